@@ -1,0 +1,130 @@
+/*
+ * nerf_hip.h -- C ABI of libnerf_hip.so: NeRF volume rendering for AMD MI355X (gfx950).
+ *
+ * The reference (nerf-pytorch inside Jiankai-Sun/nerf-loc) has no FFI on this path: every
+ * step is a PyTorch eager op.  Each entry point below therefore replaces a *function* of the
+ * reference, cited as file:line under /root/reference; nerf_loc_amd/hip.py binds them with
+ * ctypes and the Python host code keeps the reference's function names and signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - row-major, contiguous, float32 unless stated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued asynchronously on it, nothing here synchronises or allocates;
+ *   - return value: 0 on success, a negative NERF_E_* code otherwise; nerf_last_error()
+ *     then returns a message for the calling thread.  NaN/Inf in data is never an error
+ *     (the reference only prints a warning: run_nerf.py:420-422).
+ *   - inputs are never written; outputs are fully overwritten.
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_OK 0
+#define NERF_E_INVALID (-1)   /* bad size, null pointer, unsupported combination */
+#define NERF_E_HIP (-2)       /* a HIP runtime call or launch failed */
+#define NERF_E_UNSUPPORTED (-3)
+
+#define NERF_PREC_F32 0       /* exact float32 MFMA (v_mfma_f32_32x32x2_f32), fmaf-chain numerics */
+#define NERF_PREC_BF16 1      /* bf16 operands, float32 accumulation (v_mfma_f32_32x32x16_bf16) */
+
+/* what nerf_mlp_forward reads as its input */
+#define NERF_IN_FEATURES 0    /* in0 = already encoded features [M, 63(+27)] (NeRF.forward)        */
+#define NERF_IN_POINTS 1      /* in0 = pts [R*S, 3], in1 = viewdirs [R, 3] or NULL (run_network)   */
+#define NERF_IN_RAYS 2        /* in0 = rays [R, ray_cols], in1 = z_vals [R, S]: pts = o + d*z made */
+                              /* in registers, never written to memory (render_rays)               */
+
+int nerf_hip_abi_version(void);
+const char* nerf_last_error(void);
+
+/* Verifies on the current device that the MFMA operand/result lane maps this library is
+ * built on hold (exact small-integer products).  Synchronises the device.  0 = ok. */
+int nerf_selftest_mfma(void);
+
+/* ---- rays ------------------------------------------------------------------------------
+ * get_rays (run_nerf_helpers.py:153-162), the view-direction normalisation, optional NDC
+ * warp (ndc_rays, run_nerf_helpers.py:175-192) and the [N, 8|11] packing of render()
+ * (run_nerf.py:95-123), in one pass.
+ *   o_in/d_in  [N,3] each, or both NULL to generate the H x W pixel grid (N = H*W) from
+ *              c2w [3,4] and the intrinsics fx, fy, cx, cy;
+ *   c2w_view   optional second pose [3,4]: view directions come from it while origins and
+ *              directions come from c2w (the c2w_staticcam case, run_nerf.py:105-107);
+ *   near_arr/far_arr optional per-ray bounds [N]; otherwise the scalars are used;
+ *   rays_out   [N, 8] or, with use_viewdirs, [N, 11].                                     */
+int nerf_make_rays(int n_rays, int H, int W, const float* o_in, const float* d_in,
+                   const float* c2w, const float* c2w_view,
+                   float fx, float fy, float cx, float cy,
+                   float near, float far, const float* near_arr, const float* far_arr,
+                   int use_viewdirs, int ndc, float ndc_focal, float ndc_near,
+                   float* rays_out, void* stream);
+
+/* Stratified depths, run_nerf.py:363-385.  t_vals [S] = linspace(0,1,S) as the host's torch
+ * computes it; t_rand [R,S] uniform variates or NULL (perturb = 0).  z_out [R,S].          */
+int nerf_z_vals(const float* rays, int ray_cols, int R, int S, const float* t_vals,
+                const float* t_rand, int lindisp, float* z_out, void* stream);
+
+/* Embedder.embed as a standalone op (run_nerf_helpers.py:15-45): x [M,3] ->
+ * out [M, (include_input ? 3 : 0) + 6*multires] = [x, sin(2^0 x), cos(2^0 x), ...].  The fused
+ * network kernel below never calls it; it exists for callers that use get_embedder directly. */
+int nerf_embed(const float* x, long long M, int multires, int include_input, float* out,
+               void* stream);
+
+/* ---- network ---------------------------------------------------------------------------
+ * NeRF(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4]) of run_nerf_helpers.py:67-119,
+ * together with the positional encoding (run_nerf_helpers.py:15-63) and the flatten /
+ * expand / concatenate / chunk logic of run_network and batchify (run_nerf.py:27-51).
+ *
+ * Weights are first re-laid-out into the MFMA fragment stream the kernel consumes.
+ *   tensors_host: HOST array of device pointers in state_dict order: with use_viewdirs 24
+ *   entries (pts_linears.0..7 weight,bias; views_linears.0; feature_linear; alpha_linear;
+ *   rgb_linear), otherwise 20 (pts_linears.0..7; views_linears.0 (ignored, may be NULL);
+ *   output_linear with output_ch rows, 4 or 5).                                            */
+size_t nerf_mlp_packed_bytes(int precision, int use_viewdirs);
+int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs, int output_ch,
+                  int precision, void* packed_out, void* stream);
+
+/* raw_out [M, output_ch] with M = R*S (NERF_IN_FEATURES: M = R, S = 1).  With use_viewdirs
+ * the output is [rgb(3), sigma] (run_nerf_helpers.py:115).                                 */
+int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int output_ch,
+                     int input_mode, const float* in0, const float* in1,
+                     int R, int S, int ray_cols, float* raw_out, void* stream);
+
+/* ---- compositing -----------------------------------------------------------------------
+ * raw2outputs, run_nerf.py:268-311 (and nerf_utils.py:344-395).  raw [R,S,raw_ch] (raw_ch 4
+ * or 5; channels 0-2 colour, 3 density), z_vals [R,S], rays_d read from d_ptr with row
+ * stride d_stride floats (so rays+3 with stride ray_cols works), noise [R,S] already scaled
+ * or NULL.  Outputs rgb [R,3], disp [R], acc [R], depth [R], weights [R,S]; any may be NULL.
+ * disp is NaN where acc == 0, like the reference.                                          */
+int nerf_raw2outputs(const float* raw, int raw_ch, const float* z_vals, const float* d_ptr,
+                     int d_stride, const float* noise, int R, int S, int white_bkgd,
+                     float* rgb, float* disp, float* acc, float* depth, float* weights,
+                     void* stream);
+
+/* ---- hierarchical sampling -------------------------------------------------------------
+ * sample_pdf (run_nerf_helpers.py:196-239) plus the surrounding mid-point, sort(cat) and
+ * z_std code of render_rays (run_nerf.py:397-401, 418).
+ *   bins    [R, nb] with row stride bins_stride; if bins_are_z != 0 the pointer holds
+ *           z_vals [R, nb+1] instead and bins = .5*(z[1:]+z[:-1]) are formed on the fly;
+ *   weights [R, nb-1] with row stride w_stride (pass weights+1 and stride S for [...,1:-1]);
+ *   u       [n_u] shared by all rays (u_per_ray = 0) or [R, n_u] (u_per_ray = 1);
+ *   z_samples [R, n_u], inds [R, n_u] (int32 searchsorted results), z_std [R]: optional;
+ *   z_sorted  [R, n_z + n_u]: optional, sorted union of z_vals [R, n_z] and the samples.
+ * The float32 arithmetic follows ATen's CPU kernels operation by operation, so indices and
+ * samples are bit-identical to the reference on CPU for identical inputs.                  */
+int nerf_sample_pdf(const float* bins, int bins_stride, int bins_are_z, int nb,
+                    const float* weights, int w_stride,
+                    const float* u, int n_u, int u_per_ray, int R,
+                    const float* z_vals, int n_z,
+                    float* z_samples, int32_t* inds, float* z_sorted, float* z_std,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

@@ -1,0 +1,694 @@
+// Fused NeRF MLP for gfx950: positional encoding + 8x256 skip MLP + heads in ONE kernel.
+//
+// Replaces Embedder.embed (run_nerf_helpers.py:44-45), run_network / batchify
+// (run_nerf.py:27-51) and NeRF.forward (run_nerf_helpers.py:96-119).
+//
+// Design (see mlp_layout.h for the operand conventions):
+//   * a wavefront owns 64 (bf16) or 32 (f32) samples and carries them through all 11 matrix
+//     products; activations live in VGPR/AGPRs the whole time: the accumulator tile of one
+//     layer IS the B operand of the next (bf16: after relu + v_cvt_pk_bf16_f32);
+//   * weights are the A operand.  They are streamed as 1 KiB fragments through an 8 x 16 KiB
+//     LDS ring by global_load_lds (LDS-DMA, no VGPR staging), prefetched PREFETCH stages ahead
+//     behind a counted s_waitcnt vmcnt(N) and one raw s_barrier per stage; the 4 waves of the
+//     workgroup share every fragment (ds_read_b128, lane-linear, conflict-free);
+//   * persistent grid (one 256-thread workgroup per CU, 512 registers per lane): the ring
+//     keeps streaming across sample tiles, the stream wraps around at the end of the network;
+//   * positions (o + d z), sin/cos features and the per-ray view encoding are computed in
+//     registers from 44 B/ray + 4 B/sample; nothing but raw[.,4] is written back.
+// Bound: MFMA.  1 186 816 algorithmic FLOP per sample (1 212 416 issued with padding).
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace nerf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NSTAGE = 8;                   // LDS ring slots of STAGE_BYTES
+constexpr int PREFETCH = 4;                 // stages in flight beyond the one being made ready (<= NSTAGE-3)
+constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
+constexpr int LDS_BYTES = RING_BYTES + BIAS_TILES_VD * BIAS_TILE_BYTES;
+constexpr int MLP_THREADS = 256;
+static_assert(PREFETCH <= NSTAGE - 3, "a slot may be refilled only two stages after its last read");
+static_assert(PREFETCH * 4 <= 63, "vmcnt is a 6-bit counter");
+
+#define NERF_VMCNT_KEEP "16"                 // = PREFETCH stages x 4 LDS-DMA loads per wave and stage
+static_assert(PREFETCH * 4 == 16, "NERF_VMCNT_KEEP must equal PREFETCH * 4");
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+struct MlpArgs {
+    const unsigned char* packed;   // fragment stream, then the bias block
+    int n_stages;                  // stages per network pass
+    int n_bias_tiles;
+    int mode;                      // NERF_IN_*
+    const float* in0;
+    const float* in1;
+    int R, S, ray_cols;
+    long long M;                   // samples
+    float* out;
+};
+
+// ------------------------------------------------------------------------------------------
+// weight stream: LDS ring fed by LDS-DMA
+// ------------------------------------------------------------------------------------------
+struct Pipe {
+    const unsigned char* src_lane;   // packed + wave * 4 KiB + lane * 16
+    unsigned char* lds;              // ring base
+    unsigned wave_off;               // wave * 4 KiB: this wave's quarter of every stage
+    unsigned lane16;                 // lane * 16
+    int n_stages;
+    int issue_src;                   // next source stage (wraps at n_stages)
+    unsigned issue_slot;             // next ring slot to fill
+    unsigned read_off;               // byte offset of the slot being read
+    unsigned next_read_slot;
+
+    __device__ __forceinline__ void issue() {
+        const unsigned char* g = src_lane + (size_t)issue_src * STAGE_BYTES;
+        unsigned char* l = lds + issue_slot * STAGE_BYTES + wave_off;
+        // 4 x 1 KiB per wave; the LDS address is wave-uniform base + lane*16 (+ the same immediate)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 3072, 0);
+        issue_src = (issue_src + 1 == n_stages) ? 0 : issue_src + 1;
+        issue_slot = (issue_slot + 1) & (NSTAGE - 1);
+    }
+    // Issue one more stage, then make the oldest outstanding one visible to the workgroup.
+    __device__ __forceinline__ void advance() {
+        issue();
+        asm volatile("s_waitcnt vmcnt(" NERF_VMCNT_KEEP ")" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ void next_stage() {
+        read_off = next_read_slot * STAGE_BYTES;
+        next_read_slot = (next_read_slot + 1) & (NSTAGE - 1);
+    }
+    // Called before fragment `pos` (position in the pass) is consumed.  After full unrolling
+    // `pos` is a constant and exactly one branch per 8 fragments survives.
+    __device__ __forceinline__ void tick(int pos) {
+        if ((pos & (STAGE_FRAGS - 1)) == 0) next_stage();
+        if ((pos & (STAGE_FRAGS - 1)) == STAGE_FRAGS / 2) advance();
+    }
+    __device__ __forceinline__ const unsigned char* frag(int pos) const {
+        return lds + read_off + (pos & (STAGE_FRAGS - 1)) * FRAG_BYTES + lane16;
+    }
+};
+
+__device__ __forceinline__ void pipe_start(Pipe& p, const MlpArgs& a, unsigned char* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    p.src_lane = a.packed + wave * 4096 + lane * 16;
+    p.lds = lds;
+    p.wave_off = wave * 4096;
+    p.lane16 = lane * 16;
+    p.n_stages = a.n_stages;
+    p.issue_src = 0;
+    p.issue_slot = 0;
+    p.next_read_slot = 0;
+    p.read_off = 0;
+    // biases: n_bias_tiles x 32 floats behind the ring
+    const float* bsrc = reinterpret_cast<const float*>(a.packed + (size_t)a.n_stages * STAGE_BYTES);
+    float* bdst = reinterpret_cast<float*>(lds + RING_BYTES);
+    for (int i = threadIdx.x; i < a.n_bias_tiles * 32; i += MLP_THREADS) bdst[i] = bsrc[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PREFETCH; ++i) p.issue();
+    p.advance();   // stage 0 ready
+}
+
+// ------------------------------------------------------------------------------------------
+// encodings, computed by the lane for ITS k-slots (mlp_layout.h)
+// ------------------------------------------------------------------------------------------
+template <bool FAST>
+__device__ __forceinline__ void sincos_any(float x, float& s, float& c) {
+    if (FAST) {
+        // v_sin/v_cos take revolutions and need |x| <= 256: reduce with v_fract first
+        const float r = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
+        s = __builtin_amdgcn_sinf(r);
+        c = __builtin_amdgcn_cosf(r);
+    } else {
+        sincosf(x, &s, &c);
+    }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void encode_point(float px, float py, float pz, int h, float (&v)[32]) {
+    const float sc = h ? 32.0f : 1.0f;   // upper lane half: frequencies 2^5 .. 2^9
+    const float p[3] = {px * sc, py * sc, pz * sc};
+#pragma unroll
+    for (int fl = 0; fl < 5; ++fl) {
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            float s, c;
+            sincos_any<FAST>(p[c3] * (float)(1 << fl), s, c);   // exact: power-of-two scaling
+            v[(fl * 3 + c3) * 2 + 0] = s;
+            v[(fl * 3 + c3) * 2 + 1] = c;
+        }
+    }
+    v[30] = h ? pz : px;
+    v[31] = h ? 0.0f : py;
+}
+
+template <bool FAST>
+__device__ __forceinline__ void encode_view(float dx, float dy, float dz, int h, float (&v)[16]) {
+    const float sc = h ? 4.0f : 1.0f;    // upper lane half: frequencies 2^2, 2^3
+    const float p[3] = {dx * sc, dy * sc, dz * sc};
+#pragma unroll
+    for (int fl = 0; fl < 2; ++fl) {
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            float s, c;
+            sincos_any<FAST>(p[c3] * (float)(1 << fl), s, c);
+            v[(fl * 3 + c3) * 2 + 0] = s;
+            v[(fl * 3 + c3) * 2 + 1] = c;
+        }
+    }
+    v[12] = h ? 0.0f : dx;
+    v[13] = h ? 0.0f : dy;
+    v[14] = h ? 0.0f : dz;
+    v[15] = 0.0f;
+}
+
+// Fetch the encoded inputs of sample m (clamped) for lane half h.
+template <bool VD, bool FAST>
+__device__ __forceinline__ void load_encoded(const MlpArgs& a, long long m, int h, float (&pe)[32], float (&vw)[16]) {
+    if (a.mode == NERF_IN_FEATURES) {
+        const int ch = VD ? 90 : 63;
+        const float* f = a.in0 + m * ch;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int i0 = pe_slot_feature(0, q), i1 = pe_slot_feature(1, q);
+            const int idx = h ? i1 : i0;
+            pe[q] = idx >= 0 ? f[idx] : 0.0f;
+        }
+        if (VD) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i0 = view_slot_feature(0, q), i1 = view_slot_feature(1, q);
+                const int idx = h ? i1 : i0;
+                vw[q] = idx >= 0 ? f[63 + idx] : 0.0f;
+            }
+        }
+        return;
+    }
+    const long long ray = m / a.S;
+    float px, py, pz;
+    const float* vsrc;
+    if (a.mode == NERF_IN_RAYS) {
+        const float* r = a.in0 + ray * a.ray_cols;
+        const float z = a.in1[m];
+        // pts = rays_o + rays_d * z (run_nerf.py:387): product and sum rounded separately
+        px = fadd(r[0], fmul(r[3], z));
+        py = fadd(r[1], fmul(r[4], z));
+        pz = fadd(r[2], fmul(r[5], z));
+        vsrc = r + 8;
+    } else {
+        const float* q = a.in0 + m * 3;
+        px = q[0]; py = q[1]; pz = q[2];
+        vsrc = a.in1 + ray * 3;
+    }
+    encode_point<FAST>(px, py, pz, h, pe);
+    if (VD) encode_view<FAST>(vsrc[0], vsrc[1], vsrc[2], h, vw);
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 kernel: 2 column tiles (64 samples) per wave
+// ------------------------------------------------------------------------------------------
+constexpr int NCT = 2;
+
+__device__ __forceinline__ f32x16 bias_tile(const unsigned char* lds, int tile, int h) {
+    // accumulator register r holds output row (r & 3) + 8 (r >> 2) + 4 h
+    const f32x4* b = reinterpret_cast<const f32x4*>(lds + RING_BYTES + tile * BIAS_TILE_BYTES + h * 16);
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 q = b[g * 2];
+        acc[4 * g + 0] = q[0]; acc[4 * g + 1] = q[1]; acc[4 * g + 2] = q[2]; acc[4 * g + 3] = q[3];
+    }
+    return acc;
+}
+
+template <int N>
+__device__ __forceinline__ void mma_run_bf16(Pipe& p, int pos, f32x16 (&acc)[NCT], const bf16x8 (*b)[NCT]) {
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        p.tick(pos + s);
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(p.frag(pos + s));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b[s][ct], acc[ct], 0, 0, 0);
+    }
+}
+
+template <bool RELU>
+__device__ __forceinline__ void to_operand(const f32x16& acc, bf16x8& lo, bf16x8& hi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = RELU ? fmaxf(acc[j], 0.0f) : acc[j];
+        const float b = RELU ? fmaxf(acc[8 + j], 0.0f) : acc[8 + j];
+        lo[j] = (__bf16)a;
+        hi[j] = (__bf16)b;
+    }
+}
+
+// One hidden layer: NT output tiles; k = [pe (4 k-steps)] [hidden KH k-steps] [view (2 k-steps)]
+template <int NT, bool PE, int KH, bool VW, bool RELU>
+__device__ __forceinline__ void layer_bf16(Pipe& p, int& pos, int& btile, int h, const bf16x8 (&pe)[4][NCT],
+                                           const bf16x8 (&hin)[16][NCT], const bf16x8 (&vw)[2][NCT],
+                                           bf16x8 (&hout)[16][NCT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 acc[NCT];
+        acc[0] = bias_tile(p.lds, btile + t, h);
+#pragma unroll
+        for (int ct = 1; ct < NCT; ++ct) acc[ct] = acc[0];
+        if (PE) { mma_run_bf16<4>(p, pos, acc, &pe[0]); pos += 4; }
+        if (KH) { mma_run_bf16<KH>(p, pos, acc, &hin[0]); pos += KH; }
+        if (VW) { mma_run_bf16<2>(p, pos, acc, &vw[0]); pos += 2; }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) to_operand<RELU>(acc[ct], hout[2 * t][ct], hout[2 * t + 1][ct]);
+    }
+    btile += NT;
+}
+
+template <bool VD, int OUT_CH>
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mlp_bf16_kernel(MlpArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    Pipe p;
+    pipe_start(p, a, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const long long n_tiles = (a.M + 255) / 256;
+
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        bf16x8 pe[4][NCT], vw[2][NCT];
+        long long m_of[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const long long m = tile * 256 + wave * 64 + ct * 32 + c;
+            m_of[ct] = m;
+            float pv[32], vv[16];
+            load_encoded<VD, true>(a, m < a.M ? m : a.M - 1, h, pv, vv);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pe[ks][ct][j] = (__bf16)pv[ks * 8 + j];
+            if (VD) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vw[ks][ct][j] = (__bf16)vv[ks * 8 + j];
+            }
+        }
+
+        bf16x8 A[16][NCT], B[16][NCT];
+        int pos = 0, bt = 0;
+        layer_bf16<8, true, 0, false, true>(p, pos, bt, h, pe, A, vw, A);    // L0: pe -> A (hin unused)
+        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, A, vw, B);  // L1
+        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, B, vw, A);  // L2
+        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, A, vw, B);  // L3
+        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, B, vw, A);  // L4
+        layer_bf16<8, true, 16, false, true>(p, pos, bt, h, pe, A, vw, B);   // L5: [pe, h]
+        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, B, vw, A);  // L6
+        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, A, vw, B);  // L7 -> B
+
+        float o0[NCT], o1[NCT], o2[NCT], o3[NCT], o4[NCT];
+        if (VD) {
+            // feature (no activation) -> A ; alpha = row 3 of the 9th tile
+            layer_bf16<8, false, 16, false, false>(p, pos, bt, h, pe, B, vw, A);
+            {
+                f32x16 acc[NCT];
+                acc[0] = bias_tile(p.lds, bt, h);
+                acc[1] = acc[0];
+                mma_run_bf16<16>(p, pos, acc, &B[0]);
+                pos += 16; bt += 1;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) o3[ct] = acc[ct][3];
+            }
+            // views layer: [feature, view encoding] -> 128, relu  (into B[0..7])
+            layer_bf16<4, false, 16, true, true>(p, pos, bt, h, pe, A, vw, B);
+            // rgb: 128 -> 3 (rows 0..2 of one tile)
+            {
+                f32x16 acc[NCT];
+                acc[0] = bias_tile(p.lds, bt, h);
+                acc[1] = acc[0];
+                mma_run_bf16<8>(p, pos, acc, &B[0]);
+                pos += 8; bt += 1;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) { o0[ct] = acc[ct][0]; o1[ct] = acc[ct][1]; o2[ct] = acc[ct][2]; o4[ct] = 0.f; }
+            }
+        } else {
+            f32x16 acc[NCT];
+            acc[0] = bias_tile(p.lds, bt, h);
+            acc[1] = acc[0];
+            mma_run_bf16<16>(p, pos, acc, &B[0]);
+            pos += 16; bt += 1;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                o0[ct] = acc[ct][0]; o1[ct] = acc[ct][1]; o2[ct] = acc[ct][2]; o3[ct] = acc[ct][3];
+                o4[ct] = acc[ct][0];   // row 4 sits in register 0 of the upper lane half
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const long long m = m_of[ct];
+            if (m < a.M) {
+                if (OUT_CH == 4) {
+                    if (h == 0) *reinterpret_cast<float4*>(a.out + m * 4) = make_float4(o0[ct], o1[ct], o2[ct], o3[ct]);
+                } else {
+                    float* o = a.out + m * OUT_CH;
+                    if (h == 0) { o[0] = o0[ct]; o[1] = o1[ct]; o[2] = o2[ct]; o[3] = o3[ct]; }
+                    else { o[4] = o4[ct]; }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
+
+// ------------------------------------------------------------------------------------------
+// f32 kernel: exact float32 MFMA (k-ordered fmaf chain), 1 column tile (32 samples) per wave
+// ------------------------------------------------------------------------------------------
+template <int NF>
+__device__ __forceinline__ void mma_run_f32(Pipe& p, int pos, f32x16& acc, const float* b) {
+#pragma unroll
+    for (int g = 0; g < NF; ++g) {
+        p.tick(pos + g);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.frag(pos + g));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], b[4 * g + j], acc, 0, 0, 0);
+    }
+}
+
+template <int NT, bool PE, int HT /*hidden input tiles*/, bool VW, bool RELU>
+__device__ __forceinline__ void layer_f32(Pipe& p, int& pos, int& btile, int h, const float (&pe)[32],
+                                          const float (&hin)[8][16], const float (&vw)[16], float (&hout)[8][16]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 acc = bias_tile(p.lds, btile + t, h);
+        if (PE) { mma_run_f32<8>(p, pos, acc, &pe[0]); pos += 8; }
+        if (HT) { mma_run_f32<HT * 4>(p, pos, acc, &hin[0][0]); pos += HT * 4; }
+        if (VW) { mma_run_f32<4>(p, pos, acc, &vw[0]); pos += 4; }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hout[t][e] = RELU ? fmaxf(acc[e], 0.0f) : acc[e];
+    }
+    btile += NT;
+}
+
+template <bool VD, int OUT_CH>
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mlp_f32_kernel(MlpArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    Pipe p;
+    pipe_start(p, a, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const long long n_tiles = (a.M + 127) / 128;
+
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long m = tile * 128 + wave * 32 + c;
+        float pe[32], vw[16];
+        load_encoded<VD, false>(a, m < a.M ? m : a.M - 1, h, pe, vw);
+
+        float A[8][16], B[8][16];
+        int pos = 0, bt = 0;
+        layer_f32<8, true, 0, false, true>(p, pos, bt, h, pe, A, vw, A);   // L0
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, A, vw, B);  // L1
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, B, vw, A);  // L2
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, A, vw, B);  // L3
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, B, vw, A);  // L4
+        layer_f32<8, true, 8, false, true>(p, pos, bt, h, pe, A, vw, B);   // L5
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, B, vw, A);  // L6
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, A, vw, B);  // L7 -> B
+
+        float o0, o1, o2, o3, o4 = 0.f;
+        if (VD) {
+            layer_f32<8, false, 8, false, false>(p, pos, bt, h, pe, B, vw, A);   // feature -> A
+            {
+                f32x16 acc = bias_tile(p.lds, bt, h);
+                mma_run_f32<32>(p, pos, acc, &B[0][0]);
+                pos += 32; bt += 1;
+                o3 = acc[3];
+            }
+            layer_f32<4, false, 8, true, true>(p, pos, bt, h, pe, A, vw, B);     // views -> B[0..3]
+            {
+                f32x16 acc = bias_tile(p.lds, bt, h);
+                mma_run_f32<16>(p, pos, acc, &B[0][0]);
+                pos += 16; bt += 1;
+                o0 = acc[0]; o1 = acc[1]; o2 = acc[2];
+            }
+        } else {
+            f32x16 acc = bias_tile(p.lds, bt, h);
+            mma_run_f32<32>(p, pos, acc, &B[0][0]);
+            pos += 32; bt += 1;
+            o0 = acc[0]; o1 = acc[1]; o2 = acc[2]; o3 = acc[3]; o4 = acc[0];
+        }
+        if (m < a.M) {
+            if (OUT_CH == 4) {
+                if (h == 0) *reinterpret_cast<float4*>(a.out + m * 4) = make_float4(o0, o1, o2, o3);
+            } else {
+                float* o = a.out + m * OUT_CH;
+                if (h == 0) { o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; }
+                else { o[4] = o4; }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packer
+// ------------------------------------------------------------------------------------------
+struct PackArgs {
+    NetDesc net;
+    const float* t[24];
+    int bf16;
+    int total_frags;
+    unsigned char* out;
+};
+
+__device__ __forceinline__ const float* pack_row(const PackArgs& a, const LayerDesc& L, int tile, int r, bool bias, int& row) {
+    row = -1;
+    switch (L.kind) {
+        case LK_HIDDEN:
+            row = tile * 32 + r;
+            if (row >= L.out_dim) { row = -1; return nullptr; }
+            return a.t[bias ? L.b_idx : L.w_idx];
+        case LK_FEATURE_ALPHA:
+            if (tile < 8) { row = tile * 32 + r; return a.t[bias ? L.b_idx : L.w_idx]; }
+            if (r == 3) { row = 0; return a.t[bias ? L.b2_idx : L.w2_idx]; }
+            return nullptr;
+        default:   // LK_RGB, LK_OUTPUT: rows 0..out_dim-1 of a single tile
+            if (r < L.out_dim) { row = r; return a.t[bias ? L.b_idx : L.w_idx]; }
+            return nullptr;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int F = gid >> 6, lane = gid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    if (F < a.total_frags) {
+        int f = F, li = 0;
+        for (; li < a.net.n_layers; ++li) {
+            const int nf = a.net.layer[li].n_tiles * frags_per_tile(a.net.layer[li], a.bf16);
+            if (f < nf) break;
+            f -= nf;
+        }
+        const LayerDesc& L = a.net.layer[li];
+        const int fpt = frags_per_tile(L, a.bf16);
+        const int tile = f / fpt, g = f - tile * fpt;
+        int row;
+        const float* W = pack_row(a, L, tile, r, false, row);
+        const int n_el = a.bf16 ? 8 : 4;
+        float vals[8];
+        for (int j = 0; j < n_el; ++j) {
+            int col = -1;
+            if (a.bf16) {
+                const int npe = L.has_pe ? 4 : 0, nh = L.hid_feats / 16;
+                if (g < npe) { const int ft = pe_slot_feature(h, 8 * g + j); col = ft < 0 ? -1 : L.pe_col + ft; }
+                else if (g < npe + nh) { const int hs = g - npe; col = L.hid_col + 16 * hs + 8 * (j >> 2) + 4 * h + (j & 3); }
+                else { const int ft = view_slot_feature(h, 8 * (g - npe - nh) + j); col = ft < 0 ? -1 : L.view_col + ft; }
+            } else {
+                const int npe = L.has_pe ? 8 : 0, nh = L.hid_feats / 8;
+                if (g < npe) { const int ft = pe_slot_feature(h, 4 * g + j); col = ft < 0 ? -1 : L.pe_col + ft; }
+                else if (g < npe + nh) {
+                    const int gh = g - npe, T = gh >> 2, e = (gh & 3) * 4 + j;
+                    col = L.hid_col + 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
+                } else { const int ft = view_slot_feature(h, 4 * (g - npe - nh) + j); col = ft < 0 ? -1 : L.view_col + ft; }
+            }
+            vals[j] = (W && col >= 0) ? W[(size_t)row * L.in_dim + col] : 0.0f;
+        }
+        unsigned char* dst = a.out + (size_t)F * FRAG_BYTES + lane * 16;
+        if (a.bf16) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (__bf16)vals[j];
+            *reinterpret_cast<bf16x8*>(dst) = v;
+        } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(vals[0], vals[1], vals[2], vals[3]);
+        }
+    } else {
+        // bias block: n_bias_tiles x 32 floats in natural row order
+        const int bi = gid - a.total_frags * 64;
+        if (bi >= a.net.n_bias_tiles * 32) return;
+        int t = bi >> 5, li = 0;
+        const int rr = bi & 31;
+        for (; li < a.net.n_layers; ++li) {
+            if (t < a.net.layer[li].n_tiles) break;
+            t -= a.net.layer[li].n_tiles;
+        }
+        int row;
+        const float* Bp = pack_row(a, a.net.layer[li], t, rr, true, row);
+        reinterpret_cast<float*>(a.out + (size_t)a.total_frags * FRAG_BYTES)[bi] = Bp ? Bp[row] : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA lane-map self test (exact small integers, asymmetric operands)
+// ------------------------------------------------------------------------------------------
+__global__ void selftest_kernel(int* bad) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    auto Aval = [](int i, int k) { return (float)((i * 3 + k * 5) % 7 - 3); };
+    auto Bval = [](int k, int j) { return (float)((k * 2 + j * 7) % 5 - 2); };
+    int nbad = 0;
+    {   // bf16 32x32x16: A[row r][k = 8h + j], B[k = 8h + j][col r]
+        bf16x8 fa, fb;
+        for (int j = 0; j < 8; ++j) { fa[j] = (__bf16)Aval(r, 8 * h + j); fb[j] = (__bf16)Bval(8 * h + j, r); }
+        f32x16 acc;
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h, col = r;
+            float ref = 0.f;
+            for (int k = 0; k < 16; ++k) ref += Aval(row, k) * Bval(k, col);
+            if (acc[e] != ref) ++nbad;
+        }
+    }
+    {   // f32 32x32x2: A[i = r][k = h], B[k = h][j = r]
+        f32x16 acc;
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Aval(r, h), Bval(h, r), acc, 0, 0, 0);
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h, col = r;
+            const float ref = Aval(row, 0) * Bval(0, col) + Aval(row, 1) * Bval(1, col);
+            if (acc[e] != ref) ++nbad;
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+extern "C" int nerf_selftest_mfma(void) {
+    int* d = nullptr;
+    NERF_HIP_CHECK(hipMalloc(&d, sizeof(int)));
+    NERF_HIP_CHECK(hipMemset(d, 0, sizeof(int)));
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, 0, d);
+    NERF_LAUNCH_CHECK();
+    int hbad = -1;
+    NERF_HIP_CHECK(hipMemcpy(&hbad, d, sizeof(int), hipMemcpyDeviceToHost));
+    NERF_HIP_CHECK(hipFree(d));
+    if (hbad != 0) {
+        set_error("MFMA lane-map self test: %d mismatching accumulator elements", hbad);
+        return NERF_E_HIP;
+    }
+    return NERF_OK;
+}
+
+static int frag_total(int precision, int use_viewdirs) {
+    if (precision == NERF_PREC_BF16) return use_viewdirs ? FRAGS_BF16_VD : FRAGS_BF16_NOVD;
+    return use_viewdirs ? FRAGS_F32_VD : FRAGS_F32_NOVD;
+}
+
+extern "C" size_t nerf_mlp_packed_bytes(int precision, int use_viewdirs) {
+    if (precision != NERF_PREC_BF16 && precision != NERF_PREC_F32) return 0;
+    return (size_t)frag_total(precision, use_viewdirs) * FRAG_BYTES +
+           (size_t)(use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD) * BIAS_TILE_BYTES;
+}
+
+extern "C" int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs, int output_ch, int precision,
+                             void* packed_out, void* stream) {
+    NERF_REQUIRE(tensors_host && packed_out, "nerf_mlp_pack: null pointer");
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_F32, "nerf_mlp_pack: unknown precision %d", precision);
+    if (use_viewdirs) NERF_REQUIRE(output_ch == 4, "nerf_mlp_pack: with view directions the output is [rgb, sigma] (4 channels)");
+    else NERF_REQUIRE(output_ch == 4 || output_ch == 5, "nerf_mlp_pack: output_ch must be 4 or 5, got %d", output_ch);
+    PackArgs a;
+    a.net = make_net_desc(use_viewdirs != 0, output_ch);
+    a.bf16 = precision == NERF_PREC_BF16;
+    a.total_frags = total_frags(a.net, a.bf16);
+    NERF_REQUIRE(a.total_frags == frag_total(precision, use_viewdirs) &&
+                     a.net.n_bias_tiles == (use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD),
+                 "nerf_mlp_pack: internal layout mismatch");
+    const int n_t = use_viewdirs ? 24 : 20;
+    for (int i = 0; i < 24; ++i) a.t[i] = i < n_t ? tensors_host[i] : nullptr;
+    for (int i = 0; i < n_t; ++i)
+        if (use_viewdirs || (i != 16 && i != 17)) NERF_REQUIRE(a.t[i], "nerf_mlp_pack: tensor %d is null", i);
+    a.out = static_cast<unsigned char*>(packed_out);
+    const int threads = a.total_frags * 64 + a.net.n_bias_tiles * 32;
+    hipLaunchKernelGGL(pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, as_stream(stream), a);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+}
+
+extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int output_ch, int input_mode,
+                                const float* in0, const float* in1, int R, int S, int ray_cols, float* raw_out,
+                                void* stream) {
+    NERF_REQUIRE(packed && in0 && raw_out, "nerf_mlp_forward: null pointer");
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_F32, "nerf_mlp_forward: unknown precision %d", precision);
+    NERF_REQUIRE(R >= 0 && S >= 1, "nerf_mlp_forward: bad shape R=%d S=%d", R, S);
+    if (use_viewdirs) NERF_REQUIRE(output_ch == 4, "nerf_mlp_forward: output_ch must be 4 with view directions");
+    else NERF_REQUIRE(output_ch == 4 || output_ch == 5, "nerf_mlp_forward: output_ch must be 4 or 5");
+    switch (input_mode) {
+        case NERF_IN_FEATURES: NERF_REQUIRE(S == 1, "nerf_mlp_forward: feature input is flat (S = 1)"); break;
+        case NERF_IN_POINTS: NERF_REQUIRE(!use_viewdirs || in1, "nerf_mlp_forward: view directions missing"); break;
+        case NERF_IN_RAYS:
+            NERF_REQUIRE(in1, "nerf_mlp_forward: z_vals missing");
+            NERF_REQUIRE(ray_cols >= (use_viewdirs ? 11 : 8), "nerf_mlp_forward: rays need %d columns, got %d",
+                         use_viewdirs ? 11 : 8, ray_cols);
+            break;
+        default: NERF_REQUIRE(false, "nerf_mlp_forward: unknown input mode %d", input_mode);
+    }
+    if (output_ch == 4) NERF_REQUIRE(((uintptr_t)raw_out & 15) == 0, "nerf_mlp_forward: raw_out must be 16-byte aligned");
+    NERF_REQUIRE(((uintptr_t)packed & 15) == 0, "nerf_mlp_forward: packed weights must be 16-byte aligned");
+    const long long M = (long long)R * S;
+    if (M == 0) return NERF_OK;
+    MlpArgs a;
+    a.packed = static_cast<const unsigned char*>(packed);
+    a.n_stages = frag_total(precision, use_viewdirs) / STAGE_FRAGS;
+    a.n_bias_tiles = use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD;
+    a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
+    const int per_tile = precision == NERF_PREC_BF16 ? 256 : 128;
+    const long long n_tiles = (M + per_tile - 1) / per_tile;
+    const int grid = (int)(n_tiles < cu_count() ? n_tiles : cu_count());
+    hipStream_t st = as_stream(stream);
+    if (precision == NERF_PREC_BF16) {
+        if (use_viewdirs) hipLaunchKernelGGL((mlp_bf16_kernel<true, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+        else if (output_ch == 4) hipLaunchKernelGGL((mlp_bf16_kernel<false, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((mlp_bf16_kernel<false, 5>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+    } else {
+        if (use_viewdirs) hipLaunchKernelGGL((mlp_f32_kernel<true, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+        else if (output_ch == 4) hipLaunchKernelGGL((mlp_f32_kernel<false, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((mlp_f32_kernel<false, 5>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+    }
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+}

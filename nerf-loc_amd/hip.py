@@ -1,0 +1,264 @@
+"""ctypes binding of libnerf_hip.so (C ABI: include/nerf_hip.h).
+
+PyTorch is used only for device memory and streams: every wrapper takes torch
+tensors, checks device / dtype / contiguity, and passes raw device pointers and
+the current HIP stream to the library.  There is no CPU fallback: if the
+library is missing or a tensor is not on a GPU the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnerf_hip.so")
+
+PREC_F32, PREC_BF16 = 0, 1
+IN_FEATURES, IN_POINTS, IN_RAYS = 0, 1, 2
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
+
+_c_float_p = ctypes.c_void_p   # device pointers travel as integers
+
+_SIGNATURES = {
+    "nerf_hip_abi_version": (ctypes.c_int, []),
+    "nerf_last_error": (ctypes.c_char_p, []),
+    "nerf_selftest_mfma": (ctypes.c_int, []),
+    "nerf_make_rays": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p,
+                                      _c_float_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_float, ctypes.c_float, _c_float_p, ctypes.c_void_p]),
+    "nerf_z_vals": (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
+                                   ctypes.c_int, _c_float_p, ctypes.c_void_p]),
+    "nerf_embed": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, _c_float_p,
+                                  ctypes.c_void_p]),
+    "nerf_mlp_packed_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "nerf_mlp_pack": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_void_p]),
+    "nerf_mlp_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        _c_float_p, ctypes.c_void_p]),
+    "nerf_raw2outputs": (ctypes.c_int, [_c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, _c_float_p,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
+                                        _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "nerf_sample_pdf": (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p,
+                                       ctypes.c_int, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p, _c_float_p,
+                                       _c_float_p, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+class NerfHipError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names include/nerf_hip.h declares; used by the CPU-side load test."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load the shared library once.  Raises if it has not been built
+    (python __graft_entry__.py build, or make -C nerf-loc_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NerfHipError("%s is missing: build it with `make -C nerf-loc_amd/csrc` "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(code, what):
+    if code != 0:
+        msg = lib().nerf_last_error().decode("utf-8", "replace")
+        raise NerfHipError("%s failed (%d): %s" % (what, code, msg))
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _f32(t, name, device=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
+    if not t.is_cuda:
+        raise ValueError("%s must live on a GPU (got %s); this engine has no CPU path" % (name, t.device))
+    if device is not None and t.device != device:
+        raise ValueError("%s is on %s but %s was expected" % (name, t.device, device))
+    if t.dtype != torch.float32:
+        raise ValueError("%s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def selftest():
+    _check(lib().nerf_selftest_mfma(), "nerf_selftest_mfma")
+
+
+# --------------------------------------------------------------------------- rays
+def make_rays(H, W, K, c2w=None, rays_o=None, rays_d=None, near=0.0, far=1.0, use_viewdirs=False, ndc=False,
+              c2w_view=None, device=None):
+    """[N, 8|11] ray batch from a pose (pixel grid) or from given origins/directions."""
+    fx, fy, cx, cy = float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
+    near_arr = far_arr = None
+    if isinstance(near, torch.Tensor):
+        near_arr, near = _f32(near.reshape(-1), "near"), 0.0
+    if isinstance(far, torch.Tensor):
+        far_arr, far = _f32(far.reshape(-1), "far"), 0.0
+    if rays_o is None:
+        c2w = _f32(torch.as_tensor(c2w)[:3, :4], "c2w")
+        dev = c2w.device
+        n = int(H) * int(W)
+        cv = _f32(torch.as_tensor(c2w_view)[:3, :4], "c2w_staticcam", dev) if c2w_view is not None else None
+        o_in = d_in = None
+    else:
+        o_in, d_in = _f32(rays_o.reshape(-1, 3), "rays_o"), _f32(rays_d.reshape(-1, 3), "rays_d")
+        dev = d_in.device
+        n = d_in.shape[0]
+        cv = None
+    out = torch.empty((n, 11 if use_viewdirs else 8), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().nerf_make_rays(n, int(H), int(W), _ptr(o_in), _ptr(d_in), _ptr(c2w) if rays_o is None else None,
+                                    _ptr(cv), fx, fy, cx, cy, float(near), float(far), _ptr(near_arr), _ptr(far_arr),
+                                    int(bool(use_viewdirs)), int(bool(ndc)), fx, 1.0, _ptr(out), _stream(out)),
+               "nerf_make_rays")
+    return out
+
+
+_LINSPACE_CACHE = {}
+
+
+def linspace01(n, device):
+    """torch.linspace(0, 1, n) evaluated on the HOST (its float32 rounding is
+    part of the reference's results) and cached per device."""
+    key = (int(n), str(device))
+    t = _LINSPACE_CACHE.get(key)
+    if t is None:
+        t = torch.linspace(0.0, 1.0, steps=int(n), dtype=torch.float32, device="cpu").to(device)
+        _LINSPACE_CACHE[key] = t
+    return t
+
+
+def z_vals(rays, n_samples, lindisp=False, t_rand=None, t_vals=None):
+    rays = _f32(rays, "rays")
+    R, cols = rays.shape
+    tv = _f32(t_vals, "t_vals", rays.device) if t_vals is not None else linspace01(n_samples, rays.device)
+    tr = _f32(t_rand, "t_rand", rays.device) if t_rand is not None else None
+    if tr is not None and tuple(tr.shape) != (R, n_samples):
+        raise ValueError("t_rand must be [%d, %d], got %s" % (R, n_samples, tuple(tr.shape)))
+    out = torch.empty((R, n_samples), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        _check(lib().nerf_z_vals(_ptr(rays), cols, R, int(n_samples), _ptr(tv), _ptr(tr), int(bool(lindisp)),
+                                 _ptr(out), _stream(out)), "nerf_z_vals")
+    return out
+
+
+def embed(x, multires, include_input=True):
+    x = _f32(x, "inputs")
+    if x.shape[-1] != 3:
+        raise ValueError("positional encoding expects [..., 3] inputs, got %s" % (tuple(x.shape),))
+    flat = x.reshape(-1, 3)
+    out = torch.empty((flat.shape[0], (3 if include_input else 0) + 6 * multires), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().nerf_embed(_ptr(flat), flat.shape[0], int(multires), int(bool(include_input)), _ptr(out),
+                                _stream(out)), "nerf_embed")
+    return out.reshape(tuple(x.shape[:-1]) + (out.shape[-1],))
+
+
+# --------------------------------------------------------------------------- network
+def mlp_pack(tensors, use_viewdirs, output_ch, precision):
+    """tensors: list of device tensors in state_dict order (None allowed for the
+    unused views_linears of a network without view directions)."""
+    dev = next(t for t in tensors if t is not None).device
+    keep = [None if t is None else _f32(t.detach(), "weight %d" % i, dev) for i, t in enumerate(tensors)]
+    arr = (ctypes.c_void_p * len(keep))(*[None if t is None else t.data_ptr() for t in keep])
+    nbytes = lib().nerf_mlp_packed_bytes(precision, int(bool(use_viewdirs)))
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().nerf_mlp_pack(arr, int(bool(use_viewdirs)), int(output_ch), precision,
+                                   ctypes.c_void_p(packed.data_ptr()), _stream(packed)), "nerf_mlp_pack")
+    return packed
+
+
+def mlp_forward(packed, precision, use_viewdirs, output_ch, mode, in0, in1, R, S, ray_cols=0):
+    in0 = _f32(in0, "mlp input")
+    in1 = _f32(in1, "mlp second input", in0.device) if in1 is not None else None
+    out = torch.empty((R * S, output_ch), dtype=torch.float32, device=in0.device)
+    with torch.cuda.device(in0.device):
+        _check(lib().nerf_mlp_forward(ctypes.c_void_p(packed.data_ptr()), precision, int(bool(use_viewdirs)),
+                                      int(output_ch), mode, _ptr(in0), _ptr(in1), int(R), int(S), int(ray_cols),
+                                      _ptr(out), _stream(out)), "nerf_mlp_forward")
+    return out
+
+
+# --------------------------------------------------------------------------- compositing / sampling
+def raw2outputs(raw, z, d, d_stride, noise=None, white_bkgd=False, want_weights=True, want_rgb=True,
+                want_depth=True):
+    """raw [R,S,4|5], z [R,S]; d: tensor whose data pointer is the first direction
+    component of ray 0 and whose rows are d_stride floats apart."""
+    raw, z = _f32(raw, "raw"), _f32(z, "z_vals", raw.device)
+    R, S, ch = raw.shape
+    if tuple(z.shape) != (R, S):
+        raise ValueError("z_vals %s does not match raw %s" % (tuple(z.shape), tuple(raw.shape)))
+    dev = raw.device
+    noise = _f32(noise, "noise", dev) if noise is not None else None
+    f = dict(dtype=torch.float32, device=dev)
+    rgb = torch.empty((R, 3), **f) if want_rgb else None
+    acc = torch.empty((R,), **f)
+    depth = torch.empty((R,), **f) if want_depth else None
+    disp = torch.empty((R,), **f) if want_depth else None
+    weights = torch.empty((R, S), **f) if want_weights else None
+    with torch.cuda.device(dev):
+        _check(lib().nerf_raw2outputs(_ptr(raw), ch, _ptr(z), ctypes.c_void_p(d.data_ptr()), int(d_stride),
+                                      _ptr(noise), R, S, int(bool(white_bkgd)), _ptr(rgb), _ptr(disp), _ptr(acc),
+                                      _ptr(depth), _ptr(weights), _stream(raw)), "nerf_raw2outputs")
+    return rgb, disp, acc, weights, depth
+
+
+def sample_pdf(bins, weights, u, bins_are_z=False, z_vals=None, want_samples=True, want_inds=False,
+               want_sorted=False, want_std=False):
+    """bins [R,nb] (or z_vals [R,nb+1] with bins_are_z), weights: 2-D float32
+    view with unit inner stride (row stride may exceed its width); u [n] or [R,n]."""
+    if not (bins.is_cuda and weights.is_cuda):
+        raise ValueError("sample_pdf inputs must live on a GPU; this engine has no CPU path")
+    if bins.dtype != torch.float32 or weights.dtype != torch.float32:
+        raise ValueError("sample_pdf inputs must be float32")
+    if bins.stride(-1) != 1:
+        bins = bins.contiguous()
+    if weights.stride(-1) != 1:
+        weights = weights.contiguous()
+    R = bins.shape[0]
+    nb = bins.shape[1] - (1 if bins_are_z else 0)
+    if weights.shape[0] != R or weights.shape[1] != nb - 1:
+        raise ValueError("weights must be [%d, %d], got %s" % (R, nb - 1, tuple(weights.shape)))
+    dev = bins.device
+    u = _f32(u, "u", dev)
+    per_ray = int(u.dim() == 2)
+    n_u = u.shape[-1]
+    if per_ray and u.shape[0] != R:
+        raise ValueError("u must be [%d, n] or [n]" % R)
+    f = dict(dtype=torch.float32, device=dev)
+    zs = torch.empty((R, n_u), **f) if want_samples else None
+    inds = torch.empty((R, n_u), dtype=torch.int32, device=dev) if want_inds else None
+    n_z = 0
+    zsorted = None
+    if want_sorted:
+        z_vals = _f32(z_vals, "z_vals", dev)
+        n_z = z_vals.shape[1]
+        zsorted = torch.empty((R, n_z + n_u), **f)
+    std = torch.empty((R,), **f) if want_std else None
+    with torch.cuda.device(dev):
+        _check(lib().nerf_sample_pdf(_ptr(bins), bins.stride(0), int(bool(bins_are_z)), nb, _ptr(weights),
+                                     weights.stride(0), _ptr(u), n_u, per_ray, R, _ptr(z_vals) if want_sorted else None,
+                                     n_z, _ptr(zs), None if inds is None else ctypes.c_void_p(inds.data_ptr()),
+                                     _ptr(zsorted), _ptr(std), _stream(bins)), "nerf_sample_pdf")
+    return zs, inds, zsorted, std

@@ -1,0 +1,146 @@
+"""Drop-in for nerf_loc_coarse_fine/utils/nerf_utils.py: the private copy of the
+render path that the NeRF-Loc detector uses to produce its rendered_rgb /
+rendered_depth / raw-volume inputs (nerf_utils.py:16-395).
+
+Differences of this flavour from run_nerf.py, all kept: the network is
+hard-wired (D=8, W=256, L=10/4, view directions, 64 samples, no fine pass);
+render() returns [rgb, disp, acc, depth, extras]; render_rays adds depth_map and
+honours nerf_render_rgb / nerf_render_depth; render_path returns numpy arrays
+(rgbs, disps, raws, depths) and always asks for the raw volume.
+"""
+import numpy as np
+import torch
+
+from . import hip
+from . import render as _r
+from .helpers import NeRF, get_embedder, get_rays, to8b, ndc_rays, sample_pdf  # re-exported names
+from .render import run_network, NetworkQuery, load_checkpoint
+
+
+def create_nerf_model(args, ckpt_path=None, device='cuda:0', near=0.1, far=9.):
+    """nerf_utils.py:16-85.  `args` only needs nerf_render_rgb / nerf_render_depth."""
+    embed_fn, input_ch = get_embedder(10, 10)
+    embeddirs_fn, input_ch_views = get_embedder(4, 10)
+    model = NeRF(D=8, W=256, input_ch=input_ch, output_ch=4, skips=[4], input_ch_views=input_ch_views,
+                 use_viewdirs=True).to(device)
+    network_query_fn = NetworkQuery(embed_fn, embeddirs_fn, 1024 * 64)
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn,
+        'perturb': 1,
+        'N_importance': 0,
+        'network_fine': None,
+        'N_samples': 64,
+        'network_fn': model,
+        'use_viewdirs': True,
+        'white_bkgd': False,
+        'raw_noise_std': 1e0,
+        'nerf_render_rgb': args.nerf_render_rgb,
+        'nerf_render_depth': args.nerf_render_depth,
+        'ndc': False,
+    }
+    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    render_kwargs_test['retraw'] = True
+    for kw in (render_kwargs_train, render_kwargs_test):
+        kw.update({'near': near, 'far': far})
+    start = 0
+    if ckpt_path is not None:
+        render_kwargs_test, start = load_nerf_model(render_kwargs_test, ckpt_path)
+    return render_kwargs_train, render_kwargs_test, start
+
+
+def load_nerf_model(render_kwargs_test, ckpt_path):
+    """nerf_utils.py:88-105: ckpt_path is a LIST of checkpoint files; the last one
+    is loaded into network_fn (only network_fn_state_dict is used)."""
+    start = 0
+    ckpts = ckpt_path
+    if len(ckpts) > 0:
+        net = render_kwargs_test['network_fn']
+        dev = next(net.parameters()).device
+        ckpt = torch.load(ckpts[-1], map_location=dev, weights_only=True)
+        start = ckpt['global_step']
+        net.load_state_dict(ckpt['network_fn_state_dict'])
+    return render_kwargs_test, start
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, nerf_render_rgb=True,
+                nerf_render_depth=True):
+    """nerf_utils.py:344-395: as run_nerf.raw2outputs, but maps that are switched
+    off come back as None (all five when both switches are off)."""
+    if not nerf_render_rgb and not nerf_render_depth:
+        return None, None, None, None, None
+    d = rays_d.reshape(-1, 3)
+    if d.dtype != torch.float32 or d.stride(-1) != 1:
+        d = d.float().contiguous()
+    noise = _r._density_noise(raw[..., 3].shape, raw_noise_std, pytest, raw.device)
+    return hip.raw2outputs(raw, z_vals, d, d.stride(0), noise, white_bkgd, want_rgb=nerf_render_rgb,
+                           want_depth=nerf_render_depth)
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
+                nerf_render_rgb=True, nerf_render_depth=True):
+    """nerf_utils.py:248-342: coarse pass only; returns rgb_map, disp_map,
+    acc_map, depth_map (+ raw).  N_importance / network_fine are accepted and
+    ignored, as in the reference."""
+    if not nerf_render_rgb and not nerf_render_depth:
+        ret = {'rgb_map': None, 'disp_map': None, 'acc_map': None, 'depth_map': None}
+        if retraw:
+            ret['raw'] = _r.render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=True,
+                                        lindisp=lindisp, perturb=perturb, pytest=pytest)['raw']
+        return ret
+    ret = _r.render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=retraw, lindisp=lindisp,
+                         perturb=perturb, N_importance=0, network_fine=None, white_bkgd=white_bkgd,
+                         raw_noise_std=raw_noise_std, verbose=verbose, pytest=pytest, _with_depth=True,
+                         _render_rgb=nerf_render_rgb, _render_depth=nerf_render_depth)
+    for k in ret:
+        if k in ['disp_map'] or ret[k] is None:
+            continue
+        if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+            print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """nerf_utils.py:233-245."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: (None if v[0] is None else (v[0] if len(v) == 1 else torch.cat(v, 0))) for k, v in all_ret.items()}
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=False, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """nerf_utils.py:153-219: returns [rgb_map, disp_map, acc_map, depth_map, extras]."""
+    rays_flat, sh = _r._build_rays(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam)
+    all_ret = batchify_rays(rays_flat, chunk, **kwargs)
+    for k in all_ret:
+        if all_ret[k] is not None:
+            all_ret[k] = torch.reshape(all_ret[k], sh + list(all_ret[k].shape[1:]))
+    k_extract = ['rgb_map', 'disp_map', 'acc_map', 'depth_map']
+    ret_list = [all_ret[k] for k in k_extract]
+    ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
+    return ret_list + [ret_dict]
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, savedir=None, render_factor=0):
+    """nerf_utils.py:107-151: per pose one render; returns numpy (rgbs, disps,
+    raws, depths) stacked over poses."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H = H // render_factor
+        W = W // render_factor
+        focal = focal / render_factor
+    rgbs, disps, raws, depths = [], [], [], []
+    for i, c2w in enumerate(render_poses):
+        rgb, disp, acc, depth, extra = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        rgbs.append(rgb.cpu().detach().numpy())
+        disps.append(disp.cpu().detach().numpy())
+        raws.append(extra['raw'].cpu().detach().numpy())
+        depths.append(depth.cpu().detach().numpy())
+        if savedir is not None:
+            _r._save_frame(savedir, i, rgbs[-1], extra['raw'] if render_kwargs.get('retraw') else None)
+    return np.stack(rgbs, 0), np.stack(disps, 0), np.stack(raws, 0), np.stack(depths, 0)
