@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Throughput of the NeRF volume-rendering path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--precision bf16|fp32] [--res 800]
+
+One step = one full render of the BASELINE.json configuration 2 workload on every rank: an 800 x 800 view
+(640 000 rays), 64 coarse + 128 importance samples, D=8/W=256 networks with view directions, separate fine
+network, random-init weights ("trained-like" scaling so the scene is opaque), white background.  Rays are
+generated on the device from the pose; inputs and weights are resident in HBM before the timed region.  With
+N > 1 every rank renders its own 640 000-ray shard of an N x 640 000-ray batch (weak scaling) and one RCCL
+all-gather assembles the per-ray maps on every rank inside the timed region.
+
+Rank 0 prints ONE JSON line: rays/s over all ranks, the MFMA roofline of the network kernel (HIP events
+around every launch of it in the timed region) and the CPU oracle timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = 1186816          # 2 x 593 408 MAC (run_nerf_helpers.py:67-119 shapes), bias/activation/PE not counted
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks of MI355X
+
+
+def build_scene(device, precision, res):
+    from nerf_loc_amd import synth, helpers, render
+    H, W, K, c2w, near, far = synth.lego_camera(res, theta=30.0)
+
+    def net(seed):
+        n = helpers.NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(seed, "B").items()})
+        n = n.to(device).requires_grad_(False)
+        n.precision = precision
+        return n
+
+    q = render.NetworkQuery(helpers.get_embedder(10, 0)[0], helpers.get_embedder(4, 0)[0], 1024 * 64)
+    kwargs = dict(network_query_fn=q, perturb=0.0, N_importance=128, network_fine=net(1), N_samples=64,
+                  network_fn=net(0), use_viewdirs=True, white_bkgd=True, raw_noise_std=0.0, ndc=False, lindisp=False,
+                  near=near, far=far)
+    return H, W, K, torch.from_numpy(c2w).to(device), kwargs
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The numpy oracle (a port of the reference's CPU path, pinned to the reference by golden fixtures) on a
+    bounded sample of the same workload: the first rays of the same view, coarse + fine."""
+    from nerf_loc_amd import synth
+    from oracle import nerf_oracle as orc
+    H, W, K, c2w, near, far = synth.lego_camera(800, theta=30.0)
+    o, d = orc.get_rays(H, W, K, c2w)
+    rays = orc.pack_rays(o, d, near, far, True)
+    sc, sf = synth.make_state_dict(0, "B"), synth.make_state_dict(1, "B")
+    n = 1024
+    t0 = time.time()
+    orc.render_rays(rays[:n], sc, 64, 128, sd_fine=sf, white_bkgd=True)
+    dt = time.time() - t0
+    n2 = int(min(16384, max(n, n * seconds_target / max(dt, 1e-3))))
+    n2 -= n2 % 256
+    t0 = time.time()
+    orc.render_rays(rays[:n2], sc, 64, 128, sd_fine=sf, white_bkgd=True)
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": n2 / dt, "unit": "rays/s", "cores": int(cores), "kind": "port",
+            "sample": "first %d rays of the same 800x800 view, 64+128 samples, numpy oracle (float32, BLAS threads)" % n2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--chunk", type=int, default=1 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from nerf_loc_amd import dist as ndist, hip, render
+    import torch.distributed as tdist
+    rank, world, device = ndist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    hip.lib()
+    H, W, K, c2w, kwargs = build_scene(device, args.precision, args.res)
+    n_rays = H * W
+    keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
+
+    def step():
+        rays_flat, _ = render._build_rays(H, W, K, None, c2w, False, kwargs["near"], kwargs["far"], True, None)
+        rk = {k: v for k, v in kwargs.items() if k not in ("near", "far", "use_viewdirs", "ndc")}
+        ret = render.batchify_rays(rays_flat, args.chunk, **rk)
+        rec = ndist.pack_record(ret, keys)
+        if world > 1:
+            rec = ndist.all_gather_rows(rec, n_rays * world, n_rays)
+        return rec
+
+    def sync():
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    hip.MLP_EVENTS = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    events, hip.MLP_EVENTS = hip.MLP_EVENTS, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out[:, :3]).all()
+
+    if rank == 0:
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+        flops = [n * FLOP_PER_SAMPLE for _, _, n in events]
+        fine = [(m, f) for m, f in zip(ms, flops) if f == max(flops)]
+        ach = sum(f for _, f in fine) / (sum(m for m, _ in fine) * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        line = {
+            "metric": "rendered rays/sec (64+128 samples)", "value": n_rays * world * args.steps / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %dx%d view (%d rays/GPU), 64 coarse + 128 importance samples, "
+                                   "D8/W256 L10/4 viewdirs, separate fine net, seeded random weights, %s-MFMA mode"
+                                   % (H, W, n_rays, args.precision),
+                       "rays_per_gpu": n_rays, "chunk": args.chunk, "parallelism": "ray-shard x%d + 1 all-gather" % world},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "traffic": None, "kernel": "mlp_%s_kernel (fine pass launches: %d samples each, avg %.3f ms)"
+                                   % ("bf16" if args.precision == "bf16" else "f32", fine[0][1] // FLOP_PER_SAMPLE,
+                                      sum(m for m, _ in fine) / len(fine)),
+                         "all_launches_tflops": sum(flops) / (sum(ms) * 1e-3) / 1e12,
+                         "mlp_time_share": sum(ms) * 1e-3 / dt},
+        }
+        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""Multi-GPU layer: one process per GPU, torch.distributed over RCCL (backend
+"nccl" on ROCm) or gloo for CPU rehearsal.
+
+The reference renders on a single device (run_nerf.py:22, run_multi_nerf.py:572
+just skips finished objects); nothing on its render path communicates.  Rays are
+independent, so a ray batch is cut into contiguous shards of ceil(N/G) rays, every
+rank renders its shard with the single-GPU path, and ONE all-gather of the packed
+per-ray record assembles the maps on every rank.  The raw volume stays sharded.
+Per-object networks (multi-NeRF) are dealt round-robin with no collective at all.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+RECORD_KEYS = ("rgb_map", "disp_map", "acc_map", "depth_map", "rgb0", "disp0", "acc0", "z_std")
+_WIDTH = {"rgb_map": 3, "rgb0": 3}
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* and
+    bind this process to cuda:LOCAL_RANK.  Returns (rank, world_size, device)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+    return rank, world, device
+
+
+def world():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def shard_bounds(n, r, g):
+    """Contiguous shard [lo, hi) of rank r among g ranks: ceil(n/g) items each,
+    the tail ranks may get fewer or none."""
+    per = (n + g - 1) // g
+    lo = min(n, r * per)
+    return lo, min(n, lo + per), per
+
+
+def objects_of_rank(n_objects, r, g):
+    """Round-robin object ids of rank r (independent per-object networks)."""
+    return list(range(r, n_objects, g))
+
+
+def pack_record(ret, keys):
+    """[n, width] float32 record of the per-ray maps named in keys."""
+    cols = []
+    for k in keys:
+        v = ret[k]
+        cols.append(v.reshape(v.shape[0], -1))
+    return torch.cat(cols, -1).contiguous()
+
+
+def unpack_record(rec, keys):
+    out, c = {}, 0
+    for k in keys:
+        w = _WIDTH.get(k, 1)
+        v = rec[:, c:c + w]
+        out[k] = v if w > 1 else v[:, 0]
+        c += w
+    return out
+
+
+def all_gather_rows(local, n_total, per):
+    """One all-gather of equally padded row blocks; returns the first n_total rows."""
+    g = world()
+    if g == 1:
+        return local
+    width = local.shape[1]
+    if local.shape[0] < per:
+        pad = torch.zeros((per - local.shape[0], width), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    out = torch.empty((g * per, width), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out[:n_total]
+
+
+def render_rays_sharded(rays_flat, render_fn, keys=None):
+    """rays_flat [N, 8|11] present on every rank; render_fn(rays) -> dict of per-ray
+    tensors (e.g. lambda r: render.batchify_rays(r, chunk, **kwargs)).  Returns the
+    dict of gathered maps [N, ...], identical on all ranks."""
+    n = rays_flat.shape[0]
+    lo, hi, per = shard_bounds(n, rank(), world())
+    local = render_fn(rays_flat[lo:hi]) if hi > lo else None
+    if keys is None:
+        probe = local if local is not None else render_fn(rays_flat[:1])
+        keys = [k for k in RECORD_KEYS if k in probe]
+    width = sum(_WIDTH.get(k, 1) for k in keys)
+    if local is not None:
+        rec = pack_record(local, keys)
+    else:
+        rec = torch.zeros((0, width), dtype=torch.float32, device=rays_flat.device)
+    return unpack_record(all_gather_rows(rec, n, per), keys)

@@ -189,14 +189,26 @@ def mlp_pack(tensors, use_viewdirs, output_ch, precision):
     return packed
 
 
+# Set to a list to have every network launch bracketed by HIP events on its own stream:
+# entries are (start_event, end_event, n_samples).  Used by bench.py for the roofline figure.
+MLP_EVENTS = None
+
+
 def mlp_forward(packed, precision, use_viewdirs, output_ch, mode, in0, in1, R, S, ray_cols=0):
     in0 = _f32(in0, "mlp input")
     in1 = _f32(in1, "mlp second input", in0.device) if in1 is not None else None
     out = torch.empty((R * S, output_ch), dtype=torch.float32, device=in0.device)
+    ev = MLP_EVENTS
     with torch.cuda.device(in0.device):
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(in0.device))
         _check(lib().nerf_mlp_forward(ctypes.c_void_p(packed.data_ptr()), precision, int(bool(use_viewdirs)),
                                       int(output_ch), mode, _ptr(in0), _ptr(in1), int(R), int(S), int(ray_cols),
                                       _ptr(out), _stream(out)), "nerf_mlp_forward")
+        if ev is not None:
+            e1.record(torch.cuda.current_stream(in0.device))
+            ev.append((e0, e1, R * S))
     return out
 
 
