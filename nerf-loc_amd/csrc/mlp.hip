@@ -57,6 +57,7 @@ struct MlpArgs {
 struct Pipe {
     const unsigned char* src_lane;   // packed + wave * 4 KiB + lane * 16
     unsigned char* lds;              // ring base
+    unsigned lds_addr;               // the same as a 32-bit LDS byte address (for M0)
     unsigned wave_off;               // wave * 4 KiB: this wave's quarter of every stage
     unsigned lane16;                 // lane * 16
     int n_stages;
@@ -67,12 +68,24 @@ struct Pipe {
 
     __device__ __forceinline__ void issue() {
         const unsigned char* g = src_lane + (size_t)issue_src * STAGE_BYTES;
-        unsigned char* l = lds + issue_slot * STAGE_BYTES + wave_off;
-        // 4 x 1 KiB per wave; the LDS address is wave-uniform base + lane*16 (+ the same immediate)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 2048, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 3072, 0);
+        // LDS-DMA: 4 x 1 KiB per wave.  The LDS address is M0 + lane*16 + the instruction offset.
+        // Written as inline asm on purpose: once hipcc sees a global_load_lds it treats the
+        // LDS counter as out of order and turns every counted "s_waitcnt lgkmcnt(N)" of the
+        // fragment queue into lgkmcnt(0).  The loads are waited for by hand (advance()).
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr + issue_slot * STAGE_BYTES + wave_off);
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+            "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+            "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(g), "s"(m0v)
+            : "memory");
         issue_src = (issue_src + 1 == n_stages) ? 0 : issue_src + 1;
         issue_slot = (issue_slot + 1) & (NSTAGE - 1);
     }
@@ -102,6 +115,7 @@ __device__ __forceinline__ void pipe_start(Pipe& p, const MlpArgs& a, unsigned c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     p.src_lane = a.packed + wave * 4096 + lane * 16;
     p.lds = lds;
+    p.lds_addr = (unsigned)(size_t)(lds_ptr_t)lds;
     p.wave_off = wave * 4096;
     p.lane16 = lane * 16;
     p.n_stages = a.n_stages;
@@ -215,10 +229,8 @@ __device__ __forceinline__ void load_encoded(const MlpArgs& a, long long m, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 kernel: 2 column tiles (64 samples) per wave
+// shared by both precisions: bias tile -> accumulator layout
 // ------------------------------------------------------------------------------------------
-constexpr int NCT = 2;
-
 __device__ __forceinline__ f32x16 bias_tile(const unsigned char* lds, int tile, int h) {
     // accumulator register r holds output row (r & 3) + 8 (r >> 2) + 4 h
     const f32x4* b = reinterpret_cast<const f32x4*>(lds + RING_BYTES + tile * BIAS_TILE_BYTES + h * 16);
@@ -231,61 +243,140 @@ __device__ __forceinline__ f32x16 bias_tile(const unsigned char* lds, int tile, 
     return acc;
 }
 
-template <int N>
-__device__ __forceinline__ void mma_run_bf16(Pipe& p, int pos, f32x16 (&acc)[NCT], const bf16x8 (*b)[NCT]) {
-#pragma unroll
-    for (int s = 0; s < N; ++s) {
-        p.tick(pos + s);
-        const bf16x8 w = *reinterpret_cast<const bf16x8*>(p.frag(pos + s));
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b[s][ct], acc[ct], 0, 0, 0);
+// ------------------------------------------------------------------------------------------
+// bf16 kernel: 2 column tiles (64 samples) per wave, software-pipelined by hand:
+//   * weight fragments are read from LDS PF k-steps ahead into a 4-deep register queue;
+//   * the epilogue of an output tile (relu + v_cvt_pk_bf16_f32 into the next layer's operand
+//     registers) is cut into 16 slices that are issued under the MFMAs of the NEXT tile;
+//   * the bias of the next tile is fetched half a tile ahead.
+// The running position `pos` in the fragment stream is a compile-time constant everywhere
+// (everything below is fully unrolled), only ring slots and addresses are run-time values.
+// ------------------------------------------------------------------------------------------
+constexpr int NCT = 2;
+constexpr int PF = 3;                        // LDS read-ahead in fragments (queue depth 4)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+struct Stream {                              // position-independent view of the LDS ring
+    Pipe p;
+    unsigned slot0;                          // ring slot of stage 0 of the current pass
+    u32x4 q[4];                              // fragment queue: q[k & 3] holds fragment k
+
+    __device__ __forceinline__ const unsigned char* addr(int k) const {
+        const unsigned slot = (slot0 + (unsigned)(k >> 4)) & (NSTAGE - 1);
+        return p.lds + slot * STAGE_BYTES + (k & (STAGE_FRAGS - 1)) * FRAG_BYTES + p.lane16;
     }
+    __device__ __forceinline__ void fetch(int k) { q[k & 3] = *reinterpret_cast<const u32x4*>(addr(k)); }
+    // before fragment `pos` is consumed: at mid-stage make the next stage visible
+    __device__ __forceinline__ void tick(int pos) {
+        if ((pos & (STAGE_FRAGS - 1)) == STAGE_FRAGS / 2) p.advance();
+    }
+    __device__ __forceinline__ void end_pass(int n_frags) { slot0 = (slot0 + (unsigned)(n_frags >> 4)) & (NSTAGE - 1); }
+};
+
+__device__ __forceinline__ unsigned pack_pair(float a, float b, bool relu) {
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    if (relu) {
+        // relu on the packed pair: as signed 16-bit integers every negative bf16 is < 0
+        s16x2 i = __builtin_bit_cast(s16x2, v);
+        const s16x2 z = {0, 0};
+        i = __builtin_elementwise_max(i, z);
+        return __builtin_bit_cast(unsigned, i);
+    }
+    return __builtin_bit_cast(unsigned, v);
 }
 
-template <bool RELU>
-__device__ __forceinline__ void to_operand(const f32x16& acc, bf16x8& lo, bf16x8& hi) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float a = RELU ? fmaxf(acc[j], 0.0f) : acc[j];
-        const float b = RELU ? fmaxf(acc[8 + j], 0.0f) : acc[8 + j];
-        lo[j] = (__bf16)a;
-        hi[j] = (__bf16)b;
-    }
+// slice sl (0..15) of the epilogue of a finished tile: two accumulator registers -> one packed
+// operand dword of the next layer.  dst = &h[2t]: rows 2t <- registers 0-7, 2t+1 <- registers 8-15.
+__device__ __forceinline__ void epi_slice(const f32x16 (&accp)[NCT], u32x4 (*dst)[NCT], bool relu, int sl) {
+    const int g = sl >> 2, qd = sl & 3, ct = g >> 1, half = g & 1;
+    dst[half][ct][qd] = pack_pair(accp[ct][8 * half + 2 * qd], accp[ct][8 * half + 2 * qd + 1], relu);
 }
 
-// One hidden layer: NT output tiles; k = [pe (4 k-steps)] [hidden KH k-steps] [view (2 k-steps)]
-template <int NT, bool PE, int KH, bool VW, bool RELU>
-__device__ __forceinline__ void layer_bf16(Pipe& p, int& pos, int& btile, int h, const bf16x8 (&pe)[4][NCT],
-                                           const bf16x8 (&hin)[16][NCT], const bf16x8 (&vw)[2][NCT],
-                                           bf16x8 (&hout)[16][NCT]) {
+// One 32-row output tile: k-steps [pe KPE][hidden KH][view KVW].  `accp` comes in holding the
+// previous tile's accumulators (its epilogue into pdst is issued here, if has_prev) and leaves
+// holding this tile's.
+template <int KPE, int KH, int KVW>
+__device__ __forceinline__ void tile_bf16(Stream& st, int pos, int h, int bias_next_idx, f32x16& bias,
+                                          const u32x4 (*pe)[NCT], const u32x4 (*hin)[NCT], const u32x4 (*vw)[NCT],
+                                          f32x16 (&accp)[NCT], u32x4 (*pdst)[NCT], bool prelu, bool has_prev) {
+    constexpr int KS = KPE + KH + KVW;
+    constexpr int SPK = KS >= 16 ? 2 : 4;    // epilogue slices per k-step: done after KS/2 k-steps at the latest
+    f32x16 acc[NCT];
+    f32x16 bias_next = bias;
+    // The order below is the issue order: hipcc's scheduler would otherwise sink every LDS read
+    // next to its MFMA (one s_waitcnt lgkmcnt(0) per k-step) and bunch the epilogue in front of the
+    // tile, so each group is fenced with sched_barrier(0).  Per k-step: 1 ds_read_b128 (PF ahead),
+    // MFMA, <= 8 VALU of the previous tile's epilogue, MFMA, <= 8 VALU.
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = pos + s;
+        st.tick(k);
+        __builtin_amdgcn_sched_barrier(0);
+        st.fetch(k + PF);
+        if (s == KS / 2) bias_next = bias_tile(st.p.lds, bias_next_idx, h);
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4* b = s < KPE ? pe[s] : (s < KPE + KH ? hin[s - KPE] : vw[s - KPE - KH]);
+        const bf16x8 w = __builtin_bit_cast(bf16x8, st.q[k & 3]);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, __builtin_bit_cast(bf16x8, b[ct]),
+                                                             s == 0 ? bias : acc[ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_prev) {
+#pragma unroll
+                for (int i = 0; i < SPK / NCT; ++i) {
+                    const int sl = s * SPK + ct * (SPK / NCT) + i;
+                    if (sl < 16) epi_slice(accp, pdst, prelu, sl);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    bias = bias_next;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) accp[ct] = acc[ct];
+}
+
+// NT tiles of one layer.  (prev_dst, prev_relu, has_prev) describe the tile that ran just before
+// this layer; on return the last tile of this layer is pending in accp (destination hout + 2(NT-1)).
+template <int NT, int KPE, int KH, int KVW>
+__device__ __forceinline__ void layer_bf16(Stream& st, int& pos, int& bt, int n_bias_tiles, int h, f32x16& bias,
+                                           const u32x4 (*pe)[NCT], const u32x4 (*hin)[NCT], const u32x4 (*vw)[NCT],
+                                           f32x16 (&accp)[NCT], u32x4 (*prev_dst)[NCT], bool prev_relu, bool has_prev,
+                                           u32x4 (*hout)[NCT], bool relu) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        f32x16 acc[NCT];
-        acc[0] = bias_tile(p.lds, btile + t, h);
-#pragma unroll
-        for (int ct = 1; ct < NCT; ++ct) acc[ct] = acc[0];
-        if (PE) { mma_run_bf16<4>(p, pos, acc, &pe[0]); pos += 4; }
-        if (KH) { mma_run_bf16<KH>(p, pos, acc, &hin[0]); pos += KH; }
-        if (VW) { mma_run_bf16<2>(p, pos, acc, &vw[0]); pos += 2; }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) to_operand<RELU>(acc[ct], hout[2 * t][ct], hout[2 * t + 1][ct]);
+        tile_bf16<KPE, KH, KVW>(st, pos, h, (bt + 1) % n_bias_tiles, bias, pe, hin, vw, accp,
+                                t == 0 ? prev_dst : hout + 2 * (t - 1), t == 0 ? prev_relu : relu,
+                                t == 0 ? has_prev : true);
+        pos += KPE + KH + KVW;
+        bt += 1;
     }
-    btile += NT;
 }
 
 template <bool VD, int OUT_CH>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp_bf16_kernel(MlpArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
-    Pipe p;
-    pipe_start(p, a, lds);
+    Stream st;
+    pipe_start(st.p, a, lds);
+    st.slot0 = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, c = lane & 31;
     const long long n_tiles = (a.M + 255) / 256;
+    constexpr int NB = VD ? BIAS_TILES_VD : BIAS_TILES_NOVD;
+    constexpr int NFRAGS = VD ? FRAGS_BF16_VD : FRAGS_BF16_NOVD;
+
+#pragma unroll
+    for (int k = 0; k < PF; ++k) st.fetch(k);
+    f32x16 bias = bias_tile(lds, 0, h);
 
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        bf16x8 pe[4][NCT], vw[2][NCT];
+        u32x4 pe[4][NCT], vw[2][NCT];
         long long m_of[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
@@ -296,63 +387,46 @@ void mlp_bf16_kernel(MlpArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pe[ks][ct][j] = (__bf16)pv[ks * 8 + j];
+                for (int j = 0; j < 4; ++j) pe[ks][ct][j] = pack_pair(pv[ks * 8 + 2 * j], pv[ks * 8 + 2 * j + 1], false);
             if (VD) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) vw[ks][ct][j] = (__bf16)vv[ks * 8 + j];
+                    for (int j = 0; j < 4; ++j) vw[ks][ct][j] = pack_pair(vv[ks * 8 + 2 * j], vv[ks * 8 + 2 * j + 1], false);
             }
         }
 
-        bf16x8 A[16][NCT], B[16][NCT];
+        u32x4 A[16][NCT], B[16][NCT];
+        f32x16 accp[NCT];
         int pos = 0, bt = 0;
-        layer_bf16<8, true, 0, false, true>(p, pos, bt, h, pe, A, vw, A);    // L0: pe -> A (hin unused)
-        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, A, vw, B);  // L1
-        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, B, vw, A);  // L2
-        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, A, vw, B);  // L3
-        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, B, vw, A);  // L4
-        layer_bf16<8, true, 16, false, true>(p, pos, bt, h, pe, A, vw, B);   // L5: [pe, h]
-        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, B, vw, A);  // L6
-        layer_bf16<8, false, 16, false, true>(p, pos, bt, h, pe, A, vw, B);  // L7 -> B
+        layer_bf16<8, 4, 0, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A, false, false, A, true);         // L0: pe -> A
+        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L1
+        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, true);     // L2
+        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L3
+        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, true);     // L4
+        layer_bf16<8, 4, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L5: [pe, h]
+        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, true);     // L6
+        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L7 -> B
 
         float o0[NCT], o1[NCT], o2[NCT], o3[NCT], o4[NCT];
         if (VD) {
-            // feature (no activation) -> A ; alpha = row 3 of the 9th tile
-            layer_bf16<8, false, 16, false, false>(p, pos, bt, h, pe, B, vw, A);
-            {
-                f32x16 acc[NCT];
-                acc[0] = bias_tile(p.lds, bt, h);
-                acc[1] = acc[0];
-                mma_run_bf16<16>(p, pos, acc, &B[0]);
-                pos += 16; bt += 1;
+            layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, false);   // feature -> A (no relu)
+            layer_bf16<1, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, A + 14, false, true, A, false);  // alpha: row 3
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) o3[ct] = acc[ct][3];
-            }
-            // views layer: [feature, view encoding] -> 128, relu  (into B[0..7])
-            layer_bf16<4, false, 16, true, true>(p, pos, bt, h, pe, A, vw, B);
-            // rgb: 128 -> 3 (rows 0..2 of one tile)
-            {
-                f32x16 acc[NCT];
-                acc[0] = bias_tile(p.lds, bt, h);
-                acc[1] = acc[0];
-                mma_run_bf16<8>(p, pos, acc, &B[0]);
-                pos += 8; bt += 1;
+            for (int ct = 0; ct < NCT; ++ct) o3[ct] = accp[ct][3];
+            layer_bf16<4, 0, 16, 2>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A, false, false, B, true);       // views -> B[0..7]
+            layer_bf16<1, 0, 8, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 6, true, true, B, false);     // rgb: rows 0..2
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) { o0[ct] = acc[ct][0]; o1[ct] = acc[ct][1]; o2[ct] = acc[ct][2]; o4[ct] = 0.f; }
-            }
+            for (int ct = 0; ct < NCT; ++ct) { o0[ct] = accp[ct][0]; o1[ct] = accp[ct][1]; o2[ct] = accp[ct][2]; o4[ct] = 0.f; }
         } else {
-            f32x16 acc[NCT];
-            acc[0] = bias_tile(p.lds, bt, h);
-            acc[1] = acc[0];
-            mma_run_bf16<16>(p, pos, acc, &B[0]);
-            pos += 16; bt += 1;
+            layer_bf16<1, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, B, false);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                o0[ct] = acc[ct][0]; o1[ct] = acc[ct][1]; o2[ct] = acc[ct][2]; o3[ct] = acc[ct][3];
-                o4[ct] = acc[ct][0];   // row 4 sits in register 0 of the upper lane half
+                o0[ct] = accp[ct][0]; o1[ct] = accp[ct][1]; o2[ct] = accp[ct][2]; o3[ct] = accp[ct][3];
+                o4[ct] = accp[ct][0];   // row 4 sits in register 0 of the upper lane half
             }
         }
+        st.end_pass(NFRAGS);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             const long long m = m_of[ct];

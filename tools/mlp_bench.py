@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Times the fused network kernel alone (rays input mode) for kernel iteration and PMC runs.
+usage: python tools/mlp_bench.py [--precision bf16] [--rays 163840] [--samples 192] [--reps 5]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nerf_loc_amd import hip, synth, helpers  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--precision", default="bf16")
+ap.add_argument("--rays", type=int, default=163840)
+ap.add_argument("--samples", type=int, default=192)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--novd", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+vd = not a.novd
+sd = synth.make_state_dict(0, "B") if vd else synth.make_state_dict(0, "B", use_viewdirs=False, output_ch=4, input_ch_views=0)
+net = helpers.NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27 if vd else 0, use_viewdirs=vd)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+net = net.to(dev).requires_grad_(False)
+prec = hip.PRECISIONS[a.precision]
+packed = net.packed_weights(prec)
+rays = torch.from_numpy(synth.random_rays(a.rays, seed=0)).to(dev)
+if not vd:
+    rays = rays[:, :8].contiguous()
+z = hip.z_vals(rays, a.samples)
+out = hip.mlp_forward(packed, prec, vd, 4, hip.IN_RAYS, rays, z, a.rays, a.samples, rays.shape[1])
+torch.cuda.synchronize()
+ts = []
+for _ in range(a.reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = hip.mlp_forward(packed, prec, vd, 4, hip.IN_RAYS, rays, z, a.rays, a.samples, rays.shape[1])
+    e1.record()
+    torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+M = a.rays * a.samples
+t = float(np.median(ts))
+fl = 1186816 if vd else 2 * 492032
+print("mlp %s vd=%d: %d samples, median %.3f ms (min %.3f), %.1f TFLOP/s, %.2f us per 256-sample tile per CU, checksum %.6f"
+      % (a.precision, vd, M, t, min(ts), M * fl / t / 1e9, t * 1e3 / (M / 256 / 256), float(out.abs().mean())))
