@@ -257,6 +257,7 @@ constexpr int PF = 3;                        // LDS read-ahead in fragments (que
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Stream {                              // position-independent view of the LDS ring
     Pipe p;
@@ -276,9 +277,8 @@ struct Stream {                              // position-independent view of the
 };
 
 __device__ __forceinline__ unsigned pack_pair(float a, float b, bool relu) {
-    bf16x2 v;
-    v[0] = (__bf16)a;
-    v[1] = (__bf16)b;
+    const f32x2 f = {a, b};
+    const bf16x2 v = __builtin_convertvector(f, bf16x2);   // one v_cvt_pk_bf16_f32
     if (relu) {
         // relu on the packed pair: as signed 16-bit integers every negative bf16 is < 0
         s16x2 i = __builtin_bit_cast(s16x2, v);
@@ -296,16 +296,18 @@ __device__ __forceinline__ void epi_slice(const f32x16 (&accp)[NCT], u32x4 (*dst
     dst[half][ct][qd] = pack_pair(accp[ct][8 * half + 2 * qd], accp[ct][8 * half + 2 * qd + 1], relu);
 }
 
-// One 32-row output tile: k-steps [pe KPE][hidden KH][view KVW].  `accp` comes in holding the
-// previous tile's accumulators (its epilogue into pdst is issued here, if has_prev) and leaves
-// holding this tile's.
+// One 32-row output tile: k-steps [pe KPE][hidden KH][view KVW] accumulate into `acc`, while the
+// epilogue of the previous tile (accumulators `accp`, destination pdst) is issued, if has_prev.
+// The two accumulator sets alternate from tile to tile, so nothing is ever copied.
 template <int KPE, int KH, int KVW>
 __device__ __forceinline__ void tile_bf16(Stream& st, int pos, int h, int bias_next_idx, f32x16& bias,
                                           const u32x4 (*pe)[NCT], const u32x4 (*hin)[NCT], const u32x4 (*vw)[NCT],
-                                          f32x16 (&accp)[NCT], u32x4 (*pdst)[NCT], bool prelu, bool has_prev) {
+                                          f32x16 (&acc)[NCT], const f32x16 (&accp)[NCT], u32x4 (*pdst)[NCT],
+                                          bool prelu, bool has_prev) {
     constexpr int KS = KPE + KH + KVW;
-    constexpr int SPK = KS >= 16 ? 2 : 4;    // epilogue slices per k-step: done after KS/2 k-steps at the latest
-    f32x16 acc[NCT];
+    // epilogue slices per k-step, starting at k-step 1 (the previous tile's last MFMA result is not
+    // readable for a few cycles): done after k-step 8 (KS >= 16), 4 (KS = 8) or 3 (KS = 4)
+    constexpr int SPK = KS >= 16 ? 2 : (KS >= 8 ? 4 : 6);
     f32x16 bias_next = bias;
     // The order below is the issue order: hipcc's scheduler would otherwise sink every LDS read
     // next to its MFMA (one s_waitcnt lgkmcnt(0) per k-step) and bunch the epilogue in front of the
@@ -326,10 +328,10 @@ __device__ __forceinline__ void tile_bf16(Stream& st, int pos, int h, int bias_n
             acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, __builtin_bit_cast(bf16x8, b[ct]),
                                                              s == 0 ? bias : acc[ct], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (has_prev) {
+            if (has_prev && s >= 1) {
 #pragma unroll
                 for (int i = 0; i < SPK / NCT; ++i) {
-                    const int sl = s * SPK + ct * (SPK / NCT) + i;
+                    const int sl = (s - 1) * SPK + ct * (SPK / NCT) + i;
                     if (sl < 16) epi_slice(accp, pdst, prelu, sl);
                 }
             }
@@ -337,20 +339,19 @@ __device__ __forceinline__ void tile_bf16(Stream& st, int pos, int h, int bias_n
         }
     }
     bias = bias_next;
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) accp[ct] = acc[ct];
 }
 
 // NT tiles of one layer.  (prev_dst, prev_relu, has_prev) describe the tile that ran just before
-// this layer; on return the last tile of this layer is pending in accp (destination hout + 2(NT-1)).
+// this layer; tile number bt of the pass accumulates into accs[bt & 1]; on return the last tile of this
+// layer is pending there (destination hout + 2(NT-1)).
 template <int NT, int KPE, int KH, int KVW>
 __device__ __forceinline__ void layer_bf16(Stream& st, int& pos, int& bt, int n_bias_tiles, int h, f32x16& bias,
                                            const u32x4 (*pe)[NCT], const u32x4 (*hin)[NCT], const u32x4 (*vw)[NCT],
-                                           f32x16 (&accp)[NCT], u32x4 (*prev_dst)[NCT], bool prev_relu, bool has_prev,
+                                           f32x16 (&accs)[2][NCT], u32x4 (*prev_dst)[NCT], bool prev_relu, bool has_prev,
                                            u32x4 (*hout)[NCT], bool relu) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        tile_bf16<KPE, KH, KVW>(st, pos, h, (bt + 1) % n_bias_tiles, bias, pe, hin, vw, accp,
+        tile_bf16<KPE, KH, KVW>(st, pos, h, (bt + 1) % n_bias_tiles, bias, pe, hin, vw, accs[bt & 1], accs[(bt & 1) ^ 1],
                                 t == 0 ? prev_dst : hout + 2 * (t - 1), t == 0 ? prev_relu : relu,
                                 t == 0 ? has_prev : true);
         pos += KPE + KH + KVW;
@@ -397,7 +398,7 @@ void mlp_bf16_kernel(MlpArgs a) {
         }
 
         u32x4 A[16][NCT], B[16][NCT];
-        f32x16 accp[NCT];
+        f32x16 accp[2][NCT];     // accumulators of the current and of the previous output tile
         int pos = 0, bt = 0;
         layer_bf16<8, 4, 0, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A, false, false, A, true);         // L0: pe -> A
         layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L1
@@ -413,17 +414,21 @@ void mlp_bf16_kernel(MlpArgs a) {
             layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, false);   // feature -> A (no relu)
             layer_bf16<1, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, A + 14, false, true, A, false);  // alpha: row 3
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) o3[ct] = accp[ct][3];
+            for (int ct = 0; ct < NCT; ++ct) o3[ct] = accp[(bt - 1) & 1][ct][3];
             layer_bf16<4, 0, 16, 2>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A, false, false, B, true);       // views -> B[0..7]
             layer_bf16<1, 0, 8, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 6, true, true, B, false);     // rgb: rows 0..2
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) { o0[ct] = accp[ct][0]; o1[ct] = accp[ct][1]; o2[ct] = accp[ct][2]; o4[ct] = 0.f; }
+            for (int ct = 0; ct < NCT; ++ct) {
+                const f32x16& r = accp[(bt - 1) & 1][ct];
+                o0[ct] = r[0]; o1[ct] = r[1]; o2[ct] = r[2]; o4[ct] = 0.f;
+            }
         } else {
             layer_bf16<1, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, B, false);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                o0[ct] = accp[ct][0]; o1[ct] = accp[ct][1]; o2[ct] = accp[ct][2]; o3[ct] = accp[ct][3];
-                o4[ct] = accp[ct][0];   // row 4 sits in register 0 of the upper lane half
+                const f32x16& r = accp[(bt - 1) & 1][ct];
+                o0[ct] = r[0]; o1[ct] = r[1]; o2[ct] = r[2]; o3[ct] = r[3];
+                o4[ct] = r[0];   // row 4 sits in register 0 of the upper lane half
             }
         }
         st.end_pass(NFRAGS);
