@@ -26,15 +26,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NSTAGE = 8;                   // LDS ring slots of STAGE_BYTES
-constexpr int PREFETCH = 4;                 // stages in flight beyond the one being made ready (<= NSTAGE-3)
+#ifndef NERF_PREFETCH
+#define NERF_PREFETCH 4
+#endif
+constexpr int PREFETCH = NERF_PREFETCH;     // stages in flight beyond the one being made ready (<= NSTAGE-3)
 constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
 constexpr int LDS_BYTES = RING_BYTES + BIAS_TILES_VD * BIAS_TILE_BYTES;
 constexpr int MLP_THREADS = 256;
 static_assert(PREFETCH <= NSTAGE - 3, "a slot may be refilled only two stages after its last read");
 static_assert(PREFETCH * 4 <= 63, "vmcnt is a 6-bit counter");
 
-#define NERF_VMCNT_KEEP "16"                 // = PREFETCH stages x 4 LDS-DMA loads per wave and stage
-static_assert(PREFETCH * 4 == 16, "NERF_VMCNT_KEEP must equal PREFETCH * 4");
+#define NERF_STR2(x) #x
+#define NERF_STR(x) NERF_STR2(x)
+#if NERF_PREFETCH == 3
+#define NERF_VMCNT_KEEP "12"
+#elif NERF_PREFETCH == 4
+#define NERF_VMCNT_KEEP "16"
+#elif NERF_PREFETCH == 5
+#define NERF_VMCNT_KEEP "20"
+#else
+#error "NERF_PREFETCH must be 3, 4 or 5"
+#endif                                       // = PREFETCH stages x 4 LDS-DMA loads per wave and stage
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -92,8 +104,10 @@ struct Pipe {
     // Issue one more stage, then make the oldest outstanding one visible to the workgroup.
     __device__ __forceinline__ void advance() {
         issue();
+#ifndef NERF_EXP_NOBARRIER
         asm volatile("s_waitcnt vmcnt(" NERF_VMCNT_KEEP ")" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void next_stage() {
@@ -186,46 +200,66 @@ __device__ __forceinline__ void encode_view(float dx, float dy, float dz, int h,
     v[15] = 0.0f;
 }
 
-// Fetch the encoded inputs of sample m (clamped) for lane half h.
-template <bool VD, bool FAST>
-__device__ __forceinline__ void load_encoded(const MlpArgs& a, long long m, int h, float (&pe)[32], float (&vw)[16]) {
-    if (a.mode == NERF_IN_FEATURES) {
-        const int ch = VD ? 90 : 63;
-        const float* f = a.in0 + m * ch;
+// Raw inputs of one sample: what has to come from memory before the encodings can be computed.
+// NERF_IN_POINTS is expressed as origin = point, direction = 0, z = 0 (o + 0*0 == o exactly).
+struct RawIn {
+    float o[3], d[3], v[3], z;
+};
+
+// Issue the loads for sample m (already clamped to < M).  Nothing is computed here, so the loads
+// can be issued a whole network pass before their values are needed.
+template <bool VD>
+__device__ __forceinline__ void fetch_raw(const MlpArgs& a, unsigned m, RawIn& r) {
+    const unsigned ray = m / (unsigned)a.S;
+    if (a.mode == NERF_IN_RAYS) {
+        const float* q = a.in0 + (size_t)ray * a.ray_cols;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int i0 = pe_slot_feature(0, q), i1 = pe_slot_feature(1, q);
-            const int idx = h ? i1 : i0;
-            pe[q] = idx >= 0 ? f[idx] : 0.0f;
-        }
+        for (int k = 0; k < 3; ++k) { r.o[k] = q[k]; r.d[k] = q[3 + k]; }
         if (VD) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int i0 = view_slot_feature(0, q), i1 = view_slot_feature(1, q);
-                const int idx = h ? i1 : i0;
-                vw[q] = idx >= 0 ? f[63 + idx] : 0.0f;
-            }
+            for (int k = 0; k < 3; ++k) r.v[k] = q[8 + k];
         }
-        return;
-    }
-    const long long ray = m / a.S;
-    float px, py, pz;
-    const float* vsrc;
-    if (a.mode == NERF_IN_RAYS) {
-        const float* r = a.in0 + ray * a.ray_cols;
-        const float z = a.in1[m];
-        // pts = rays_o + rays_d * z (run_nerf.py:387): product and sum rounded separately
-        px = fadd(r[0], fmul(r[3], z));
-        py = fadd(r[1], fmul(r[4], z));
-        pz = fadd(r[2], fmul(r[5], z));
-        vsrc = r + 8;
+        r.z = a.in1[m];
     } else {
-        const float* q = a.in0 + m * 3;
-        px = q[0]; py = q[1]; pz = q[2];
-        vsrc = a.in1 + ray * 3;
+        const float* q = a.in0 + (size_t)m * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r.o[k] = q[k]; r.d[k] = 0.0f; }
+        if (VD) {
+            const float* vq = a.in1 + (size_t)ray * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) r.v[k] = vq[k];
+        }
+        r.z = 0.0f;
     }
-    encode_point<FAST>(px, py, pz, h, pe);
-    if (VD) encode_view<FAST>(vsrc[0], vsrc[1], vsrc[2], h, vw);
+}
+
+template <bool VD, bool FAST>
+__device__ __forceinline__ void encode_raw(const RawIn& r, int h, float (&pe)[32], float (&vw)[16]) {
+    // pts = rays_o + rays_d * z (run_nerf.py:387): product and sum rounded separately
+    encode_point<FAST>(fadd(r.o[0], fmul(r.d[0], r.z)), fadd(r.o[1], fmul(r.d[1], r.z)),
+                       fadd(r.o[2], fmul(r.d[2], r.z)), h, pe);
+    if (VD) encode_view<FAST>(r.v[0], r.v[1], r.v[2], h, vw);
+}
+
+// NERF_IN_FEATURES: the caller supplies the encodings; pick this lane's k-slots out of the row.
+template <bool VD>
+__device__ __forceinline__ void load_features(const MlpArgs& a, unsigned m, int h, float (&pe)[32], float (&vw)[16]) {
+    const int ch = VD ? 90 : 63;
+    const float* f = a.in0 + (size_t)m * ch;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int i0 = pe_slot_feature(0, q), i1 = pe_slot_feature(1, q);
+        const int idx = h ? i1 : i0;
+        pe[q] = idx >= 0 ? f[idx] : 0.0f;
+    }
+    if (VD) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i0 = view_slot_feature(0, q), i1 = view_slot_feature(1, q);
+            const int idx = h ? i1 : i0;
+            vw[q] = idx >= 0 ? f[63 + idx] : 0.0f;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -299,15 +333,17 @@ __device__ __forceinline__ void epi_slice(const f32x16 (&accp)[NCT], u32x4 (*dst
 // One 32-row output tile: k-steps [pe KPE][hidden KH][view KVW] accumulate into `acc`, while the
 // epilogue of the previous tile (accumulators `accp`, destination pdst) is issued, if has_prev.
 // The two accumulator sets alternate from tile to tile, so nothing is ever copied.
-template <int KPE, int KH, int KVW>
+template <int KPE, int KH, int KVW, bool early>
 __device__ __forceinline__ void tile_bf16(Stream& st, int pos, int h, int bias_next_idx, f32x16& bias,
                                           const u32x4 (*pe)[NCT], const u32x4 (*hin)[NCT], const u32x4 (*vw)[NCT],
                                           f32x16 (&acc)[NCT], const f32x16 (&accp)[NCT], u32x4 (*pdst)[NCT],
                                           bool prelu, bool has_prev) {
     constexpr int KS = KPE + KH + KVW;
-    // epilogue slices per k-step, starting at k-step 1 (the previous tile's last MFMA result is not
-    // readable for a few cycles): done after k-step 8 (KS >= 16), 4 (KS = 8) or 3 (KS = 4)
-    constexpr int SPK = KS >= 16 ? 2 : (KS >= 8 ? 4 : 6);
+    // The 16 epilogue slices of the previous tile are spread over k-steps 1..EPI_N (the previous
+    // tile's last MFMA result is not readable for a few cycles, hence not k-step 0).  When this
+    // tile reads what the epilogue writes (first tile of a layer: rows 14, 15 of its input) it must
+    // be done early, otherwise it may take the whole tile: at most one slice per MFMA gap.
+    constexpr int EPI_N = early ? (KS >= 16 ? 12 : KS / 2) : KS - 1;
     f32x16 bias_next = bias;
     // The order below is the issue order: hipcc's scheduler would otherwise sink every LDS read
     // next to its MFMA (one s_waitcnt lgkmcnt(0) per k-step) and bunch the epilogue in front of the
@@ -319,6 +355,9 @@ __device__ __forceinline__ void tile_bf16(Stream& st, int pos, int h, int bias_n
         st.tick(k);
         __builtin_amdgcn_sched_barrier(0);
         st.fetch(k + PF);
+#ifdef NERF_EXP_NOP
+        asm volatile("s_nop 7\n\ts_nop 7");
+#endif
         if (s == KS / 2) bias_next = bias_tile(st.p.lds, bias_next_idx, h);
         __builtin_amdgcn_sched_barrier(0);
         const u32x4* b = s < KPE ? pe[s] : (s < KPE + KH ? hin[s - KPE] : vw[s - KPE - KH]);
@@ -328,12 +367,12 @@ __device__ __forceinline__ void tile_bf16(Stream& st, int pos, int h, int bias_n
             acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, __builtin_bit_cast(bf16x8, b[ct]),
                                                              s == 0 ? bias : acc[ct], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (has_prev && s >= 1) {
+            if (has_prev && s >= 1 && s <= EPI_N) {
+                const int lo = (16 * (s - 1) + EPI_N - 1) / EPI_N, hi = (16 * s + EPI_N - 1) / EPI_N;
+                const int cnt = (hi < 16 ? hi : 16) - lo, first = cnt / 2;   // ct0 gap: first, ct1 gap: the rest
+                const int b0 = ct == 0 ? lo : lo + first, b1 = ct == 0 ? lo + first : lo + cnt;
 #pragma unroll
-                for (int i = 0; i < SPK / NCT; ++i) {
-                    const int sl = (s - 1) * SPK + ct * (SPK / NCT) + i;
-                    if (sl < 16) epi_slice(accp, pdst, prelu, sl);
-                }
+                for (int sl = b0; sl < b1; ++sl) epi_slice(accp, pdst, prelu, sl);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -351,13 +390,27 @@ __device__ __forceinline__ void layer_bf16(Stream& st, int& pos, int& bt, int n_
                                            u32x4 (*hout)[NCT], bool relu) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        tile_bf16<KPE, KH, KVW>(st, pos, h, (bt + 1) % n_bias_tiles, bias, pe, hin, vw, accs[bt & 1], accs[(bt & 1) ^ 1],
-                                t == 0 ? prev_dst : hout + 2 * (t - 1), t == 0 ? prev_relu : relu,
-                                t == 0 ? has_prev : true);
+        if (t == 0)
+            tile_bf16<KPE, KH, KVW, true>(st, pos, h, (bt + 1) % n_bias_tiles, bias, pe, hin, vw, accs[bt & 1],
+                                          accs[(bt & 1) ^ 1], prev_dst, prev_relu, has_prev);
+        else
+            tile_bf16<KPE, KH, KVW, false>(st, pos, h, (bt + 1) % n_bias_tiles, bias, pe, hin, vw, accs[bt & 1],
+                                           accs[(bt & 1) ^ 1], hout + 2 * (t - 1), relu, true);
         pos += KPE + KH + KVW;
         bt += 1;
     }
 }
+
+#ifdef NERF_EXP_STAMP
+// diagnostic build only: per-block cycle sums {input+encoding, layers 0-4, layer 5-7, heads, store, passes}
+__device__ unsigned long long g_stamps[256 * 8];
+#define NERF_STAMP(var)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define NERF_STAMP(var)
+#endif
 
 template <bool VD, int OUT_CH>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -376,15 +429,43 @@ void mlp_bf16_kernel(MlpArgs a) {
     for (int k = 0; k < PF; ++k) st.fetch(k);
     f32x16 bias = bias_tile(lds, 0, h);
 
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        u32x4 pe[4][NCT], vw[2][NCT];
-        long long m_of[NCT];
+    // raw inputs are fetched one whole pass ahead: with a single wave per SIMD nothing else could
+    // hide the HBM latency of a load issued where its value is needed
+    const bool feat_mode = a.mode == NERF_IN_FEATURES;
+    const unsigned Mu = (unsigned)a.M;
+    RawIn nxt[NCT];
+    if (!feat_mode && (long long)blockIdx.x < n_tiles) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            const long long m = tile * 256 + wave * 64 + ct * 32 + c;
+            const unsigned m = (unsigned)blockIdx.x * 256u + wave * 64 + ct * 32 + c;
+            fetch_raw<VD>(a, m < Mu ? m : Mu - 1, nxt[ct]);
+        }
+    }
+
+#ifdef NERF_EXP_STAMP
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, acc_t[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        NERF_STAMP(t0)
+        u32x4 pe[4][NCT], vw[2][NCT];
+        unsigned m_of[NCT];
+        RawIn cur[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) cur[ct] = nxt[ct];
+        if (!feat_mode && tile + gridDim.x < n_tiles) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const unsigned m = (unsigned)(tile + gridDim.x) * 256u + wave * 64 + ct * 32 + c;
+                fetch_raw<VD>(a, m < Mu ? m : Mu - 1, nxt[ct]);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const unsigned m = (unsigned)tile * 256u + wave * 64 + ct * 32 + c;
             m_of[ct] = m;
             float pv[32], vv[16];
-            load_encoded<VD, true>(a, m < a.M ? m : a.M - 1, h, pv, vv);
+            if (feat_mode) load_features<VD>(a, m < Mu ? m : Mu - 1, h, pv, vv);
+            else encode_raw<VD, true>(cur[ct], h, pv, vv);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -397,6 +478,7 @@ void mlp_bf16_kernel(MlpArgs a) {
             }
         }
 
+        NERF_STAMP(t1)
         u32x4 A[16][NCT], B[16][NCT];
         f32x16 accp[2][NCT];     // accumulators of the current and of the previous output tile
         int pos = 0, bt = 0;
@@ -405,10 +487,12 @@ void mlp_bf16_kernel(MlpArgs a) {
         layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, true);     // L2
         layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L3
         layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, true);     // L4
+        NERF_STAMP(t2)
         layer_bf16<8, 4, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L5: [pe, h]
         layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, true);     // L6
         layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L7 -> B
 
+        NERF_STAMP(t3)
         float o0[NCT], o1[NCT], o2[NCT], o3[NCT], o4[NCT];
         if (VD) {
             layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, false);   // feature -> A (no relu)
@@ -432,20 +516,29 @@ void mlp_bf16_kernel(MlpArgs a) {
             }
         }
         st.end_pass(NFRAGS);
+        NERF_STAMP(t4)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            const long long m = m_of[ct];
-            if (m < a.M) {
+            const unsigned m = m_of[ct];
+            if (m < Mu) {
                 if (OUT_CH == 4) {
-                    if (h == 0) *reinterpret_cast<float4*>(a.out + m * 4) = make_float4(o0[ct], o1[ct], o2[ct], o3[ct]);
+                    if (h == 0) *reinterpret_cast<float4*>(a.out + (size_t)m * 4) = make_float4(o0[ct], o1[ct], o2[ct], o3[ct]);
                 } else {
-                    float* o = a.out + m * OUT_CH;
+                    float* o = a.out + (size_t)m * OUT_CH;
                     if (h == 0) { o[0] = o0[ct]; o[1] = o1[ct]; o[2] = o2[ct]; o[3] = o3[ct]; }
                     else { o[4] = o4[ct]; }
                 }
             }
         }
+#ifdef NERF_EXP_STAMP
+        NERF_STAMP(t5)
+        acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2; acc_t[3] += t4 - t3; acc_t[4] += t5 - t4; acc_t[5] += 1;
+#endif
     }
+#ifdef NERF_EXP_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 6; ++i) g_stamps[blockIdx.x * 8 + i] = acc_t[i];
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
 
@@ -488,10 +581,24 @@ void mlp_f32_kernel(MlpArgs a) {
     const int h = lane >> 5, c = lane & 31;
     const long long n_tiles = (a.M + 127) / 128;
 
+    const bool feat_mode = a.mode == NERF_IN_FEATURES;
+    const unsigned Mu = (unsigned)a.M;
+    RawIn nxt;
+    if (!feat_mode && (long long)blockIdx.x < n_tiles) {
+        const unsigned m0 = (unsigned)blockIdx.x * 128u + wave * 32 + c;
+        fetch_raw<VD>(a, m0 < Mu ? m0 : Mu - 1, nxt);
+    }
+
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const long long m = tile * 128 + wave * 32 + c;
+        const unsigned m = (unsigned)tile * 128u + wave * 32 + c;
+        const RawIn cur = nxt;
+        if (!feat_mode && tile + gridDim.x < n_tiles) {
+            const unsigned mn = (unsigned)(tile + gridDim.x) * 128u + wave * 32 + c;
+            fetch_raw<VD>(a, mn < Mu ? mn : Mu - 1, nxt);
+        }
         float pe[32], vw[16];
-        load_encoded<VD, false>(a, m < a.M ? m : a.M - 1, h, pe, vw);
+        if (feat_mode) load_features<VD>(a, m < Mu ? m : Mu - 1, h, pe, vw);
+        else encode_raw<VD, false>(cur, h, pe, vw);
 
         float A[8][16], B[8][16];
         int pos = 0, bt = 0;
@@ -526,11 +633,11 @@ void mlp_f32_kernel(MlpArgs a) {
             pos += 32; bt += 1;
             o0 = acc[0]; o1 = acc[1]; o2 = acc[2]; o3 = acc[3]; o4 = acc[0];
         }
-        if (m < a.M) {
+        if (m < Mu) {
             if (OUT_CH == 4) {
-                if (h == 0) *reinterpret_cast<float4*>(a.out + m * 4) = make_float4(o0, o1, o2, o3);
+                if (h == 0) *reinterpret_cast<float4*>(a.out + (size_t)m * 4) = make_float4(o0, o1, o2, o3);
             } else {
-                float* o = a.out + m * OUT_CH;
+                float* o = a.out + (size_t)m * OUT_CH;
                 if (h == 0) { o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; }
                 else { o[4] = o4; }
             }
@@ -677,6 +784,12 @@ static int cu_count() {
 
 using namespace nerf;
 
+#ifdef NERF_EXP_STAMP
+extern "C" int nerf_debug_read_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? 0 : -2;
+}
+#endif
+
 extern "C" int nerf_selftest_mfma(void) {
     int* d = nullptr;
     NERF_HIP_CHECK(hipMalloc(&d, sizeof(int)));
@@ -750,6 +863,7 @@ extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewd
     NERF_REQUIRE(((uintptr_t)packed & 15) == 0, "nerf_mlp_forward: packed weights must be 16-byte aligned");
     const long long M = (long long)R * S;
     if (M == 0) return NERF_OK;
+    NERF_REQUIRE(M < (1ll << 31) - 512, "nerf_mlp_forward: at most 2^31 - 512 samples per launch, got %lld", M);
     MlpArgs a;
     a.packed = static_cast<const unsigned char*>(packed);
     a.n_stages = frag_total(precision, use_viewdirs) / STAGE_FRAGS;

@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnerf_hip.so")
+# NERF_HIP_LIB selects another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "lib", "libnerf_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
 IN_FEATURES, IN_POINTS, IN_RAYS = 0, 1, 2

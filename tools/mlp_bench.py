@@ -45,3 +45,17 @@ t = float(np.median(ts))
 fl = 1186816 if vd else 2 * 492032
 print("mlp %s vd=%d: %d samples, median %.3f ms (min %.3f), %.1f TFLOP/s, %.2f us per 256-sample tile per CU, checksum %.6f"
       % (a.precision, vd, M, t, min(ts), M * fl / t / 1e9, t * 1e3 / (M / 256 / 256), float(out.abs().mean())))
+try:   # diagnostic builds only (NERF_EXP_STAMP): per-block cycle sums of the sections of a pass
+    import ctypes
+    fn = hip.lib().nerf_debug_read_stamps
+    buf = (ctypes.c_ulonglong * (256 * 8))()
+    fn.argtypes = [ctypes.c_void_p]
+    assert fn(buf) == 0
+    st = np.array(buf[:], dtype=np.float64).reshape(256, 8)
+    per = st[:, :5] / st[:, 5:6]
+    names = ["inputs+encode", "L0-L4", "L5-L7", "heads", "store"]
+    tot = per.sum(1).mean()
+    print("stamps (cycles per pass, mean over blocks; total %.0f): " % tot +
+          ", ".join("%s %.0f (%.1f%%)" % (n, v, 100 * v / tot) for n, v in zip(names, per.mean(0))))
+except AttributeError:
+    pass
