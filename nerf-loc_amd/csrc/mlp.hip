@@ -287,7 +287,11 @@ __device__ __forceinline__ f32x16 bias_tile(const unsigned char* lds, int tile, 
 // (everything below is fully unrolled), only ring slots and addresses are run-time values.
 // ------------------------------------------------------------------------------------------
 constexpr int NCT = 2;
-constexpr int PF = 3;                        // LDS read-ahead in fragments (queue depth 4)
+#ifndef NERF_PF
+#define NERF_PF 3
+#endif
+constexpr int PF = NERF_PF;                  // LDS read-ahead in fragments
+constexpr int QD = PF + 1 <= 4 ? 4 : 8;      // queue depth (power of two > PF)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -296,13 +300,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct Stream {                              // position-independent view of the LDS ring
     Pipe p;
     unsigned slot0;                          // ring slot of stage 0 of the current pass
-    u32x4 q[4];                              // fragment queue: q[k & 3] holds fragment k
+    u32x4 q[QD];                             // fragment queue: q[k & (QD-1)] holds fragment k
 
     __device__ __forceinline__ const unsigned char* addr(int k) const {
         const unsigned slot = (slot0 + (unsigned)(k >> 4)) & (NSTAGE - 1);
         return p.lds + slot * STAGE_BYTES + (k & (STAGE_FRAGS - 1)) * FRAG_BYTES + p.lane16;
     }
-    __device__ __forceinline__ void fetch(int k) { q[k & 3] = *reinterpret_cast<const u32x4*>(addr(k)); }
+    __device__ __forceinline__ void fetch(int k) { q[k & (QD - 1)] = *reinterpret_cast<const u32x4*>(addr(k)); }
     // before fragment `pos` is consumed: at mid-stage make the next stage visible
     __device__ __forceinline__ void tick(int pos) {
         if ((pos & (STAGE_FRAGS - 1)) == STAGE_FRAGS / 2) p.advance();
@@ -361,7 +365,7 @@ __device__ __forceinline__ void tile_bf16(Stream& st, int pos, int h, int bias_n
         if (s == KS / 2) bias_next = bias_tile(st.p.lds, bias_next_idx, h);
         __builtin_amdgcn_sched_barrier(0);
         const u32x4* b = s < KPE ? pe[s] : (s < KPE + KH ? hin[s - KPE] : vw[s - KPE - KH]);
-        const bf16x8 w = __builtin_bit_cast(bf16x8, st.q[k & 3]);
+        const bf16x8 w = __builtin_bit_cast(bf16x8, st.q[k & (QD - 1)]);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, __builtin_bit_cast(bf16x8, b[ct]),
