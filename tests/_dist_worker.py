@@ -1,0 +1,52 @@
+"""Rank body of the world_size-2 gloo tests (started by test_dist_gloo.py, one process per rank).
+The render function is a deterministic stand-in with the same dict-of-maps contract as
+render.batchify_rays, so the sharding / record packing / all-gather logic runs without a GPU."""
+import json
+import sys
+
+import torch
+
+import nerf_loc_amd
+from nerf_loc_amd import dist as ndist
+
+
+def fake_render(rays):
+    o, d = rays[:, 0:3], rays[:, 3:6]
+    s = (o * d).sum(-1)
+    return {"rgb_map": torch.stack([s, 2 * s, 3 * s], -1), "disp_map": s + 1, "acc_map": s + 2,
+            "depth_map": s + 3, "rgb0": torch.stack([-s, -2 * s, -3 * s], -1), "disp0": s + 4, "acc0": s + 5,
+            "z_std": s + 6, "raw": torch.zeros(rays.shape[0], 4, 4)}
+
+
+def main():
+    out_path = sys.argv[1]
+    rank, world, device = ndist.init_from_env("gloo")
+    assert ndist.world() == world and ndist.rank() == rank
+    res = {"rank": rank, "world": world, "cases": {}}
+    for n in (1, 2, 5, 64, 1001):
+        g = torch.Generator().manual_seed(n)
+        rays = torch.randn(n, 11, generator=g)
+        calls = []
+
+        def fn(r):
+            calls.append(r.shape[0])
+            return fake_render(r)
+
+        got = ndist.render_rays_sharded(rays, fn)
+        want = fake_render(rays)
+        ok = all(torch.equal(got[k], want[k]) for k in got) and sorted(got) == sorted(k for k in want if k != "raw")
+        lo, hi, per = ndist.shard_bounds(n, rank, world)
+        res["cases"][str(n)] = {"ok": bool(ok), "rendered": calls, "shard": [lo, hi, per]}
+    # explicit key subset (coarse-only renders have no *0 maps)
+    rays = torch.randn(7, 8, generator=torch.Generator().manual_seed(3))
+    got = ndist.render_rays_sharded(rays, fake_render, keys=["rgb_map", "depth_map"])
+    res["subset_ok"] = bool(sorted(got) == ["depth_map", "rgb_map"] and torch.equal(got["rgb_map"], fake_render(rays)["rgb_map"]))
+    res["objects"] = ndist.objects_of_rank(5, rank, world)
+    torch.distributed.barrier()
+    with open(out_path + ".%d" % rank, "w") as f:
+        json.dump(res, f)
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,189 @@
+"""CPU-side checks of the C-ABI boundary and of the host logic: the library loads without a
+GPU and exports every symbol the header declares, the ctypes table agrees with the header,
+host wrappers refuse CPU tensors instead of falling back, and the shipped package never
+touches the oracle.  Nothing here launches a kernel."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import nerf_loc_amd
+from nerf_loc_amd import helpers, hip, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nerf_hip.h")
+PKG = os.path.join(ROOT, "nerf-loc_amd")
+
+
+def _header_text():
+    with open(HEADER) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("#"))
+
+
+def _header_decls():
+    """{name: (return type, [argument types])} parsed from the header's prototypes."""
+    decls = {}
+    for m in re.finditer(r"((?:const\s+)?(?:int|size_t|char)\s*\*?)\s*\b(nerf_\w+)\s*\(([^)]*)\)\s*;", _header_text()):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        arglist = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        decls[name] = (ret, arglist)
+    return decls
+
+
+def _ctype_of(decl):
+    d = decl.strip()
+    if "*" in d:
+        return "ptr"
+    d = re.sub(r"\b\w+$", "", d).strip() if len(d.split()) > 1 else d   # drop the parameter name
+    return {"int": "int", "float": "float", "long long": "longlong", "size_t": "size_t"}[d]
+
+
+_CT = {ctypes.c_int: "int", ctypes.c_float: "float", ctypes.c_longlong: "longlong", ctypes.c_size_t: "size_t",
+       ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.POINTER(ctypes.c_void_p): "ptr"}
+
+
+def test_header_declares_what_binding_binds():
+    decls = _header_decls()
+    assert len(decls) >= 11
+    assert sorted(decls) == hip.exported_symbols()
+
+
+def test_binding_signatures_match_header():
+    for name, (ret, args) in _header_decls().items():
+        res, argtypes = hip._SIGNATURES[name]
+        assert [_CT[a] for a in argtypes] == [_ctype_of(a) for a in args], name
+        assert _CT[res] == ("ptr" if "*" in ret else _ctype_of(ret + " x")), name
+
+
+def test_library_loads_and_exports_every_symbol():
+    assert os.path.exists(hip.LIB_PATH), "build the library first: python -c 'import __graft_entry__ as g; g.build()'"
+    L = ctypes.CDLL(hip.LIB_PATH)
+    for name in _header_decls():
+        assert hasattr(L, name), "libnerf_hip.so does not export %s" % name
+    lib = hip.lib()
+    assert lib.nerf_hip_abi_version() == 1
+    assert lib.nerf_last_error() is not None
+
+
+def test_packed_sizes_host_only():
+    lib = hip.lib()
+    frag, bias = 1024, 128
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 1) == 1184 * frag + 78 * bias
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 0) == 976 * frag + 65 * bias
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 1) == 2368 * frag + 78 * bias
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 0) == 1952 * frag + 65 * bias
+
+
+def test_invalid_arguments_are_refused_before_any_launch():
+    lib = hip.lib()
+    # no pointer is ever dereferenced on the host: null outputs / bad sizes must come back as NERF_E_INVALID
+    assert lib.nerf_embed(None, 4, 10, 1, None, None) == -1
+    assert b"" != lib.nerf_last_error()
+    assert lib.nerf_mlp_forward(None, 0, 1, 4, 0, None, None, 8, 1, 0, None, None) == -1
+    assert lib.nerf_mlp_forward(ctypes.c_void_p(256), 7, 1, 4, 0, ctypes.c_void_p(256), None, 8, 1, 0,
+                                ctypes.c_void_p(256), None) == -1
+    assert lib.nerf_raw2outputs(ctypes.c_void_p(256), 3, ctypes.c_void_p(256), ctypes.c_void_p(256), 3, None, 4, 8, 0,
+                                None, None, None, None, None, None) == -1
+    assert lib.nerf_sample_pdf(ctypes.c_void_p(256), 8, 0, 1, ctypes.c_void_p(256), 8, ctypes.c_void_p(256), 4, 0, 4,
+                               None, 0, None, None, None, None, None) == -1
+
+
+def test_missing_library_fails_loudly():
+    code = ("import nerf_loc_amd\nfrom nerf_loc_amd import hip\n"
+            "try:\n    hip.lib()\nexcept hip.NerfHipError as e:\n    print('LOUD', e)\n")
+    env = dict(os.environ, NERF_HIP_LIB="/nonexistent/libnerf_hip.so", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert "LOUD" in out.stdout and "no CPU fallback" in out.stdout, out.stdout + out.stderr
+
+
+def test_cpu_tensors_are_refused_not_computed():
+    x = torch.zeros(4, 3)
+    with pytest.raises(ValueError, match="GPU"):
+        hip.embed(x, 10)
+    with pytest.raises(ValueError, match="GPU"):
+        helpers.get_embedder(10)[0](x)
+    with pytest.raises(ValueError, match="GPU"):
+        helpers.sample_pdf(torch.zeros(2, 9), torch.zeros(2, 8), 4, det=True)
+    net = helpers.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True)
+    with torch.no_grad(), pytest.raises(ValueError, match="GPU"):
+        net(torch.zeros(2, 90))
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(PKG):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                with open(os.path.join(base, fn)) as f:
+                    if re.search(r"\boracle\b", f.read()):
+                        bad.append(fn)
+    assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------- host logic
+def test_nerf_module_matches_reference_checkpoint_layout():
+    net = helpers.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.make_state_dict(3, "A", use_viewdirs=True)
+    assert list(shapes) == list(sd)                                   # names AND order (run_nerf_helpers.py:77-94)
+    assert shapes == {k: tuple(v.shape) for k, v in sd.items()}
+    assert shapes["pts_linears.5.weight"] == (256, 319) and shapes["views_linears.0.weight"] == (128, 283)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    novd = helpers.NeRF(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
+    assert "output_linear.weight" in novd.state_dict() and novd.out_channels == 5 and novd.hip_supported()
+    assert not helpers.NeRF(D=4, W=128, input_ch=63).hip_supported()
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        helpers.NeRF(D=4, W=128, input_ch=63)(torch.zeros(1, 63))
+
+
+def test_get_embedder_interface():
+    fn, dim = helpers.get_embedder(10, 0)
+    assert dim == 63 and callable(fn) and fn.embedder.num_freqs == 10
+    fn, dim = helpers.get_embedder(4, 0)
+    assert dim == 27
+    ident, dim = helpers.get_embedder(10, -1)
+    assert dim == 3 and torch.equal(ident(torch.ones(2, 3)), torch.ones(2, 3))
+    with pytest.raises(NotImplementedError):
+        helpers.Embedder(include_input=True, input_dims=2, max_freq_log2=3, num_freqs=4, log_sampling=True,
+                         periodic_fns=[torch.sin, torch.cos])
+
+
+def test_misc_helpers_and_get_rays_np(golden):
+    x, y = torch.tensor([0.0, 0.5, 1.0]), torch.tensor([0.0, 0.0, 0.0])
+    mse = helpers.img2mse(x, y)
+    assert abs(float(mse) - (0.25 + 1.0) / 3) < 1e-7
+    assert abs(float(helpers.mse2psnr(mse)) + 10 * np.log10((0.25 + 1.0) / 3)) < 1e-5
+    assert helpers.to8b(np.array([-1.0, 0.5, 2.0])).tolist() == [0, 127, 255]
+    g = golden("g6_rays")
+    H, W = [int(v) for v in g["lego40_hw"]]
+    o, d = helpers.get_rays_np(H, W, g["lego40_K"], g["lego40_c2w"])
+    assert np.array_equal(np.asarray(o).reshape(-1, 3), g["lego40_o_np"].reshape(-1, 3))
+    assert np.array_equal(np.asarray(d).reshape(-1, 3), g["lego40_d_np"].reshape(-1, 3))
+    assert np.asarray(d).dtype == g["lego40_d_np"].dtype
+
+
+def test_precision_switch():
+    assert helpers.get_default_precision() == "fp32"
+    helpers.set_default_precision("bf16")
+    try:
+        net = helpers.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True)
+        assert net.precision_code() == hip.PREC_BF16
+        net.precision = "fp32"
+        assert net.precision_code() == hip.PREC_F32
+    finally:
+        helpers.set_default_precision("fp32")
+    with pytest.raises(ValueError):
+        helpers.set_default_precision("fp8")
+
+
+def test_training_entry_points_say_what_is_missing():
+    net = helpers.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True)
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(2, 90, requires_grad=True))

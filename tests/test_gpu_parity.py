@@ -214,7 +214,6 @@ def test_mlp_run_network_modes_agree(dev, golden):
     net = load_net(synth.make_state_dict(40, "A"), dev)
     e10, _ = helpers.get_embedder(10, 0)
     e4, _ = helpers.get_embedder(4, 0)
-    ref = g["out_vd_A"]
     R, S = 64, 8
     pts = T(x, dev).reshape(R, S, 3)
     vd = T(d[::S].copy(), dev)
@@ -288,15 +287,13 @@ def test_render_rays_fp32_stagewise(dev, golden, regime):
         e = maxabs(r[k], g["%s_%s" % (tag, k)])
         print("  coarse %s max abs err %.3e" % (k, e))
         assert e < 1e-4, k
-    # fine pass on the reference's own importance samples via the oracle, and free-running vs golden
-    o = orc.render_rays(rays, sc, 64, 128, sd_fine=sf, white_bkgd=True, z_samples_override=None)
+    # free-running fine pass against the golden run (the teacher-forced test below holds the 1e-4 bar)
     for k in ("rgb_map", "acc_map"):
         e_all = maxabs(r[k], g["%s_%s" % (tag, k)])
         e_mask = maxabs(r[k][mask], g["%s_%s" % (tag, k)][mask])
         print("  fine %s max abs err: all rays %.3e, conditioned rays %.3e" % (k, e_all, e_mask))
         assert e_mask < (1e-4 if regime == "A" else 5e-3), k    # regime B: free-running samples, see below
-    # free-running importance samples land in the same bins except where the pdf sits on the 1e-5 floor
-    zs_ref = g[tag + "_z_samples"]
+    # spread of the free-running importance samples; equal unless a sample sits where the pdf is on its 1e-5 floor
     assert maxabs(r["z_std"], g[tag + "_z_std"]) < 5e-4
 
 
@@ -314,7 +311,7 @@ def test_render_rays_fp32_teacher_forced(dev, golden, regime):
     assert np.array_equal(N(z), orc.z_vals_for(rays, 64))
     raw = render.run_network(rt[:, None, 0:3] + rt[:, None, 3:6] * z[:, :, None], rt[:, 8:11].contiguous(), nc,
                              *_embedders())
-    rgb0, disp0, acc0, w0, depth0 = render.raw2outputs(raw, z, rt[:, 3:6], white_bkgd=True)
+    rgb0, _, acc0, w0, depth0 = render.raw2outputs(raw, z, rt[:, 3:6], white_bkgd=True)
     o = orc.render_rays(rays, sc, 64, 0, white_bkgd=True, retraw=True)
     scale = max(1.0, np.abs(o["raw"]).max())
     print("regime %s coarse raw err %.3e (scale %.1f)" % (regime, maxabs(N(raw), o["raw"]), scale))
@@ -329,6 +326,7 @@ def test_render_rays_fp32_teacher_forced(dev, golden, regime):
     zs, inds, zsorted, std = hip.sample_pdf(z, w0[:, 1:-1], T(u, dev), bins_are_z=True, z_vals=z, want_inds=True,
                                             want_sorted=True, want_std=True)
     assert np.array_equal(N(inds), inds_ref) and np.array_equal(N(zs), zs_ref)
+    assert maxabs(N(std), zs_ref.std(-1)) < 1e-5      # torch.std(unbiased=False), run_nerf.py:418
     # fine pass on identical depths
     zf = N(zsorted)
     pts = rays[:, None, 0:3] + rays[:, None, 3:6] * zf[:, :, None]
@@ -428,36 +426,41 @@ def test_render_image_both_flavours(dev, golden):
     assert maxabs(N(depth), g["loc_depth"]) < 1e-4 * 9
     assert maxabs(N(extras["raw"]), g["loc_raw"]) < 2e-5 * max(1.0, np.abs(g["loc_raw"]).max())
     poses = torch.stack([T(g["loc_c2w"], dev)] * 2)
-    rgbs, disps, raws, depths = nerf_utils.render_path(poses, [H, W, float(g["loc_K"][0, 0])], g["loc_K"], 1024 * 32,
+    rgbs, _, raws, depths = nerf_utils.render_path(poses, [H, W, float(g["loc_K"][0, 0])], g["loc_K"], 1024 * 32,
                                                        kw_test)
     assert rgbs.shape == (2, H, W, 3) and raws.shape == (2, H, W, 64, 4) and depths.shape == (2, H, W)
     assert isinstance(rgbs, np.ndarray) and maxabs(rgbs[1], g["loc_rgb"]) < 1e-4
 
 
 # ------------------------------------------------------------------ bf16 mode end to end
-def test_render_bf16_vs_fp32(dev, golden):
-    """bf16-MFMA mode: within 1e-2 absolute and 0.1 dB PSNR of the float32 result on a well-conditioned
-    scene (regime B); regime A (random init) is reported with its conditioning mask."""
+def _psnr(a, b):
+    return -10.0 * np.log10(float(((a.astype(np.float64) - b) ** 2).mean()))
+
+
+@pytest.mark.parametrize("seed,kind", [(62, "opaque"), (66, "opaque"), (64, "mixed")])
+def test_render_bf16_vs_fp32(dev, seed, kind):
+    """bf16-MFMA mode against the float32 mode on the same rays and weights: rgb / acc within 1e-2 absolute, and
+    the PSNR against a common 30 dB target image moves by less than 0.1 dB.  Opaque scenes (every ray ends in
+    dense matter) are held to the bar on all rays; the mixed scene on the rays whose float32 result is not within
+    rounding of the 1e10-wide last interval switching on (sigma of the last sample near zero)."""
     from nerf_loc_amd import render
     rays = synth.random_rays(4096, seed=21)
-    for regime in "BA":
-        sc, sf = synth.make_state_dict(60, regime), synth.make_state_dict(61, regime)
-        out = {}
-        for prec in ("fp32", "bf16"):
-            nc, nf = load_net(sc, dev, precision=prec), load_net(sf, dev, precision=prec)
-            r = render.render_rays(T(rays, dev), nc, _query(dev), 64, retraw=True, N_importance=128, network_fine=nf,
-                                   white_bkgd=True)
-            out[prec] = {k: N(v) for k, v in r.items()}
-        err = np.abs(out["bf16"]["rgb_map"] - out["fp32"]["rgb_map"])
-        mse = float((err.astype(np.float64) ** 2).mean())
-        psnr_between = -10 * np.log10(max(mse, 1e-20))
-        # PSNR against a pseudo ground truth (the float32 render of a perturbed scene would do; here: how much
-        # would the PSNR of either render against any target differ at most) -> report the mutual PSNR
-        sig = np.abs(out["fp32"]["raw"][:, -1, 3])
-        cond = sig > 0.05
-        print("regime %s bf16 vs fp32: rgb max %.3e (conditioned rays: %.3e, %d masked), mean %.3e, mutual PSNR %.1f dB"
-              % (regime, err.max(), err[cond].max(), (~cond).sum(), err.mean(), psnr_between))
-        if regime == "B":
-            assert err[cond].max() < 1e-2
-            assert maxabs(out["bf16"]["acc_map"][cond], out["fp32"]["acc_map"][cond]) < 1e-2
-            assert psnr_between > 50.0     # 0.1 dB of PSNR change at 30 dB needs mutual PSNR > ~46 dB
+    sc, sf = synth.make_state_dict(seed, "B"), synth.make_state_dict(seed + 1, "B")
+    out = {}
+    for prec in ("fp32", "bf16"):
+        nc, nf = load_net(sc, dev, precision=prec), load_net(sf, dev, precision=prec)
+        r = render.render_rays(T(rays, dev), nc, _query(dev), 64, retraw=True, N_importance=128, network_fine=nf,
+                               white_bkgd=True)
+        out[prec] = {k: N(v) for k, v in r.items()}
+    f, b = out["fp32"], out["bf16"]
+    cond = np.ones(rays.shape[0], bool) if kind == "opaque" else np.abs(f["raw"][:, -1, 3]) > 0.05
+    err = np.abs(b["rgb_map"] - f["rgb_map"])
+    np.random.seed(5)
+    target = f["rgb_map"].astype(np.float64) + np.random.randn(*f["rgb_map"].shape) * 10 ** (-30 / 20)
+    dpsnr = abs(_psnr(b["rgb_map"][cond], target[cond]) - _psnr(f["rgb_map"][cond], target[cond]))
+    print("seed %d (%s) bf16 vs fp32: rgb max %.3e on %d conditioned rays (all rays %.3e), mean %.3e, "
+          "PSNR shift at 30 dB %.4f dB" % (seed, kind, err[cond].max(), cond.sum(), err.max(), err.mean(), dpsnr))
+    assert cond.sum() > 0.5 * cond.size
+    assert err[cond].max() < 1e-2
+    assert maxabs(b["acc_map"][cond], f["acc_map"][cond]) < 1e-2
+    assert dpsnr < 0.1
