@@ -75,6 +75,19 @@ def cpu_baseline(seconds_target=12.0):
             "sample": "first %d rays of the same 800x800 view, 64+128 samples, numpy oracle (float32, BLAS threads)" % n2}
 
 
+def pmc_traffic(precision):
+    """HBM-side bytes of one fine-pass launch of the network kernel, from the committed rocprofv3 PMC passes of
+    this same command (tools/profile_bench.sh; counters cannot be read from inside the process).  None if the
+    summary for this precision has not been collected."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % precision)))
+    try:
+        with open(paths[-1]) as f:
+            return float(json.load(f)["bytes_per_fine_launch"])
+    except (IndexError, OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +155,9 @@ def main():
                                    % (H, W, n_rays, args.precision),
                        "rays_per_gpu": n_rays, "chunk": args.chunk, "parallelism": "ray-shard x%d + 1 all-gather" % world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": None, "kernel": "mlp_%s_kernel (fine pass launches: %d samples each, avg %.3f ms)"
+                         "traffic": pmc_traffic(args.precision), "traffic_unit": "HBM-side bytes per fine-pass launch "
+                         "(rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes of this command)",
+                         "algorithmic_bytes": fine[0][1] // FLOP_PER_SAMPLE * 20 + n_rays * 44, "kernel": "mlp_%s_kernel (fine pass launches: %d samples each, avg %.3f ms)"
                                    % ("bf16" if args.precision == "bf16" else "f32", fine[0][1] // FLOP_PER_SAMPLE,
                                       sum(m for m, _ in fine) / len(fine)),
                          "all_launches_tflops": sum(flops) / (sum(ms) * 1e-3) / 1e12,
