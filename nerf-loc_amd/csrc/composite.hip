@@ -96,6 +96,118 @@ __global__ __launch_bounds__(256) void raw2outputs_kernel(
     }
 }
 
+// Backward of raw2outputs.  The reference obtains it from autograd over run_nerf.py:268-311; here the
+// forward quantities are recomputed per ray and the chain rule is applied in closed form:
+//   c = sigmoid(raw_rgb), e = exp(-sigma dist), alpha = 1 - e, T_i = prod_{j<i} (1 - alpha_j + 1e-10), w = alpha T
+//   q_i = dL/dw_i = g_rgb . c_i - [white] sum(g_rgb) + g_acc + g_depth z_i
+//   dL/dalpha_i = q_i T_i - (sum_{k>i} q_k w_k) / (1 - alpha_i + 1e-10)        (suffix sum: reverse wave scan)
+//   dL/draw_sigma_i = [raw_sigma_i + noise_i > 0] dL/dalpha_i dist_i e_i,   dL/draw_rgb_i = w_i g_rgb c_i (1 - c_i)
+// g_disp folds into g_depth / g_acc through disp = acc / depth.  One wavefront per ray, NCH chunks of 64
+// samples kept in registers.
+template <int RAW_CH, int NCH>
+__global__ __launch_bounds__(256) void raw2outputs_bwd_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ d_ptr, int d_stride,
+    const float* __restrict__ noise, int R, int S, int white_bkgd, const float* __restrict__ g_rgb,
+    const float* __restrict__ g_disp, const float* __restrict__ g_acc, const float* __restrict__ g_depth,
+    float* __restrict__ d_raw) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const float* dp = d_ptr + (size_t)ray * d_stride;
+    const float dnorm = sqrtf(fadd(fadd(fmul(dp[0], dp[0]), fmul(dp[1], dp[1])), fmul(dp[2], dp[2])));
+    const float* zr = z_vals + (size_t)ray * S;
+    const float* rr = raw + (size_t)ray * S * RAW_CH;
+    const float* nr = noise ? noise + (size_t)ray * S : nullptr;
+
+    float alpha[NCH], T[NCH], e_[NCH], dist[NCH], z[NCH], c0[NCH], c1[NCH], c2[NCH], one_m[NCH];
+    bool gate[NCH];
+    float carry = 1.0f, s_acc = 0.f, s_depth = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int i = 64 * k + lane;
+        const bool valid = i < S;
+        alpha[k] = 0.f; e_[k] = 1.f; dist[k] = 0.f; z[k] = 0.f; c0[k] = c1[k] = c2[k] = 0.f; gate[k] = false;
+        if (valid) {
+            const float* q = rr + (size_t)i * RAW_CH;
+            z[k] = zr[i];
+            dist[k] = fmul((i + 1 < S) ? fsub(zr[i + 1], z[k]) : 1e10f, dnorm);
+            float sig = q[3];
+            if (nr) sig = fadd(sig, nr[i]);
+            gate[k] = sig > 0.0f;
+            sig = fmaxf(sig, 0.0f);
+            e_[k] = expf(-fmul(sig, dist[k]));
+            alpha[k] = fsub(1.0f, e_[k]);
+            c0[k] = fdiv(1.0f, fadd(1.0f, expf(-q[0])));
+            c1[k] = fdiv(1.0f, fadd(1.0f, expf(-q[1])));
+            c2[k] = fdiv(1.0f, fadd(1.0f, expf(-q[2])));
+        }
+        one_m[k] = fadd(fsub(1.0f, alpha[k]), 1e-10f);
+        float incl = one_m[k];
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const float up = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl *= up;
+        }
+        float excl = __shfl_up(incl, 1, WAVE);
+        if (lane == 0) excl = 1.0f;
+        T[k] = carry * excl;
+        carry *= __shfl(incl, WAVE - 1, WAVE);
+        const float w = alpha[k] * T[k];
+        s_acc += w;
+        s_depth += w * z[k];
+    }
+    const float g0 = g_rgb ? g_rgb[(size_t)ray * 3 + 0] : 0.f, g1 = g_rgb ? g_rgb[(size_t)ray * 3 + 1] : 0.f,
+                g2 = g_rgb ? g_rgb[(size_t)ray * 3 + 2] : 0.f;
+    float ga = g_acc ? g_acc[ray] : 0.f, gd = g_depth ? g_depth[ray] : 0.f;
+    if (g_disp) {
+        const float gq = g_disp[ray];
+        if (gq != 0.0f) {
+            s_acc = wave_sum(s_acc);
+            s_depth = wave_sum(s_depth);
+            const float q = s_depth / s_acc;
+            if (!(q <= 1e-10f)) {            // above the clamp, or NaN (0/0), which propagates like in autograd
+                const float disp = 1.0f / q;
+                gd += gq * (-disp * disp / s_acc);
+                ga += gq * (disp * disp * s_depth / (s_acc * s_acc));
+            }
+        }
+    }
+    const float bgterm = white_bkgd ? (g0 + g1 + g2) : 0.0f;
+    float later = 0.0f;                       // sum of q_k w_k over all later chunks
+    float* outr = d_raw + (size_t)ray * S * RAW_CH;
+#pragma unroll
+    for (int k = NCH - 1; k >= 0; --k) {
+        const int i = 64 * k + lane;
+        const bool valid = i < S;
+        const float w = alpha[k] * T[k];
+        const float q = g0 * c0[k] + g1 * c1[k] + g2 * c2[k] - bgterm + ga + gd * z[k];
+        const float term = valid ? q * w : 0.0f;
+        float incl = term;                    // inclusive suffix sum within the chunk
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const float dn = __shfl_down(incl, off, WAVE);
+            if (lane + off < WAVE) incl += dn;
+        }
+        float excl = __shfl_down(incl, 1, WAVE);
+        if (lane == WAVE - 1) excl = 0.0f;
+        const float suffix = excl + later;
+        later += __shfl(incl, 0, WAVE);
+        if (valid) {
+            const float dalpha = q * T[k] - suffix / one_m[k];
+            const float dsig = gate[k] ? dalpha * dist[k] * e_[k] : 0.0f;
+            const float r0 = w * g0 * c0[k] * (1.0f - c0[k]);
+            const float r1 = w * g1 * c1[k] * (1.0f - c1[k]);
+            const float r2 = w * g2 * c2[k] * (1.0f - c2[k]);
+            if (RAW_CH == 4) {
+                reinterpret_cast<float4*>(outr)[i] = make_float4(r0, r1, r2, dsig);
+            } else {
+                float* o = outr + (size_t)i * RAW_CH;
+                o[0] = r0; o[1] = r1; o[2] = r2; o[3] = dsig; o[4] = 0.0f;
+            }
+        }
+    }
+}
+
 }  // namespace nerf
 
 using namespace nerf;
@@ -117,6 +229,40 @@ extern "C" int nerf_raw2outputs(const float* raw, int raw_ch, const float* z_val
     else
         hipLaunchKernelGGL(raw2outputs_kernel<5>, grid, block, 0, as_stream(stream), raw, z_vals, d_ptr, d_stride,
                            noise, R, S, white_bkgd, rgb, disp, acc, depth, weights);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+}
+
+template <int RAW_CH>
+static void launch_r2o_bwd(int nch, dim3 grid, dim3 block, hipStream_t st, const float* raw, const float* z,
+                           const float* d_ptr, int d_stride, const float* noise, int R, int S, int white,
+                           const float* g_rgb, const float* g_disp, const float* g_acc, const float* g_depth, float* d_raw) {
+#define NERF_R2O_CASE(n)                                                                                           \
+    case n: hipLaunchKernelGGL((raw2outputs_bwd_kernel<RAW_CH, n>), grid, block, 0, st, raw, z, d_ptr, d_stride,   \
+                               noise, R, S, white, g_rgb, g_disp, g_acc, g_depth, d_raw); break;
+    switch (nch) { NERF_R2O_CASE(1) NERF_R2O_CASE(2) NERF_R2O_CASE(3) default: NERF_R2O_CASE(4) }
+#undef NERF_R2O_CASE
+}
+
+extern "C" int nerf_raw2outputs_backward(const float* raw, int raw_ch, const float* z_vals, const float* d_ptr,
+                                         int d_stride, const float* noise, int R, int S, int white_bkgd,
+                                         const float* g_rgb, const float* g_disp, const float* g_acc,
+                                         const float* g_depth, float* d_raw, void* stream) {
+    NERF_REQUIRE(raw && z_vals && d_ptr && d_raw, "nerf_raw2outputs_backward: null pointer");
+    NERF_REQUIRE(raw_ch == 4 || raw_ch == 5, "nerf_raw2outputs_backward: raw_ch must be 4 or 5, got %d", raw_ch);
+    NERF_REQUIRE(R >= 0 && S >= 1 && d_stride >= 3, "nerf_raw2outputs_backward: bad shape R=%d S=%d d_stride=%d", R, S, d_stride);
+    if (S > 256) {
+        set_error("nerf_raw2outputs_backward: at most 256 samples per ray, got %d", S);
+        return NERF_E_UNSUPPORTED;
+    }
+    if (raw_ch == 4) NERF_REQUIRE(((uintptr_t)d_raw & 15) == 0, "nerf_raw2outputs_backward: d_raw must be 16-byte aligned");
+    if (R == 0) return NERF_OK;
+    dim3 grid((R + 3) / 4), block(4 * WAVE);
+    const int nch = (S + 63) / 64;
+    if (raw_ch == 4) launch_r2o_bwd<4>(nch, grid, block, as_stream(stream), raw, z_vals, d_ptr, d_stride, noise, R, S,
+                                       white_bkgd, g_rgb, g_disp, g_acc, g_depth, d_raw);
+    else launch_r2o_bwd<5>(nch, grid, block, as_stream(stream), raw, z_vals, d_ptr, d_stride, noise, R, S, white_bkgd,
+                           g_rgb, g_disp, g_acc, g_depth, d_raw);
     NERF_LAUNCH_CHECK();
     return NERF_OK;
 }

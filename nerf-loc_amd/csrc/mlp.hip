@@ -16,266 +16,10 @@
 //   * positions (o + d z), sin/cos features and the per-ray view encoding are computed in
 //     registers from 44 B/ray + 4 B/sample; nothing but raw[.,4] is written back.
 // Bound: MFMA.  1 186 816 algorithmic FLOP per sample (1 212 416 issued with padding).
-#include "common.h"
-#include "mlp_layout.h"
+#include "mlp_device.h"
 
 namespace nerf {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int NSTAGE = 8;                   // LDS ring slots of STAGE_BYTES
-#ifndef NERF_PREFETCH
-#define NERF_PREFETCH 4
-#endif
-constexpr int PREFETCH = NERF_PREFETCH;     // stages in flight beyond the one being made ready (<= NSTAGE-3)
-constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
-constexpr int LDS_BYTES = RING_BYTES + BIAS_TILES_VD * BIAS_TILE_BYTES;
-constexpr int MLP_THREADS = 256;
-static_assert(PREFETCH <= NSTAGE - 3, "a slot may be refilled only two stages after its last read");
-static_assert(PREFETCH * 4 <= 63, "vmcnt is a 6-bit counter");
-
-#define NERF_STR2(x) #x
-#define NERF_STR(x) NERF_STR2(x)
-#if NERF_PREFETCH == 3
-#define NERF_VMCNT_KEEP "12"
-#elif NERF_PREFETCH == 4
-#define NERF_VMCNT_KEEP "16"
-#elif NERF_PREFETCH == 5
-#define NERF_VMCNT_KEEP "20"
-#else
-#error "NERF_PREFETCH must be 3, 4 or 5"
-#endif                                       // = PREFETCH stages x 4 LDS-DMA loads per wave and stage
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-struct MlpArgs {
-    const unsigned char* packed;   // fragment stream, then the bias block
-    int n_stages;                  // stages per network pass
-    int n_bias_tiles;
-    int mode;                      // NERF_IN_*
-    const float* in0;
-    const float* in1;
-    int R, S, ray_cols;
-    long long M;                   // samples
-    float* out;
-};
-
-// ------------------------------------------------------------------------------------------
-// weight stream: LDS ring fed by LDS-DMA
-// ------------------------------------------------------------------------------------------
-struct Pipe {
-    const unsigned char* src_lane;   // packed + wave * 4 KiB + lane * 16
-    unsigned char* lds;              // ring base
-    unsigned lds_addr;               // the same as a 32-bit LDS byte address (for M0)
-    unsigned wave_off;               // wave * 4 KiB: this wave's quarter of every stage
-    unsigned lane16;                 // lane * 16
-    int n_stages;
-    int issue_src;                   // next source stage (wraps at n_stages)
-    unsigned issue_slot;             // next ring slot to fill
-    unsigned read_off;               // byte offset of the slot being read
-    unsigned next_read_slot;
-
-    __device__ __forceinline__ void issue() {
-        const unsigned char* g = src_lane + (size_t)issue_src * STAGE_BYTES;
-        // LDS-DMA: 4 x 1 KiB per wave.  The LDS address is M0 + lane*16 + the instruction offset.
-        // Written as inline asm on purpose: once hipcc sees a global_load_lds it treats the
-        // LDS counter as out of order and turns every counted "s_waitcnt lgkmcnt(N)" of the
-        // fragment queue into lgkmcnt(0).  The loads are waited for by hand (advance()).
-        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr + issue_slot * STAGE_BYTES + wave_off);
-        unsigned keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
-            "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-            "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-            "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(g), "s"(m0v)
-            : "memory");
-        issue_src = (issue_src + 1 == n_stages) ? 0 : issue_src + 1;
-        issue_slot = (issue_slot + 1) & (NSTAGE - 1);
-    }
-    // Issue one more stage, then make the oldest outstanding one visible to the workgroup.
-    __device__ __forceinline__ void advance() {
-        issue();
-#ifndef NERF_EXP_NOBARRIER
-        asm volatile("s_waitcnt vmcnt(" NERF_VMCNT_KEEP ")" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#endif
-        asm volatile("" ::: "memory");
-    }
-    __device__ __forceinline__ void next_stage() {
-        read_off = next_read_slot * STAGE_BYTES;
-        next_read_slot = (next_read_slot + 1) & (NSTAGE - 1);
-    }
-    // Called before fragment `pos` (position in the pass) is consumed.  After full unrolling
-    // `pos` is a constant and exactly one branch per 8 fragments survives.
-    __device__ __forceinline__ void tick(int pos) {
-        if ((pos & (STAGE_FRAGS - 1)) == 0) next_stage();
-        if ((pos & (STAGE_FRAGS - 1)) == STAGE_FRAGS / 2) advance();
-    }
-    __device__ __forceinline__ const unsigned char* frag(int pos) const {
-        return lds + read_off + (pos & (STAGE_FRAGS - 1)) * FRAG_BYTES + lane16;
-    }
-};
-
-__device__ __forceinline__ void pipe_start(Pipe& p, const MlpArgs& a, unsigned char* lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    p.src_lane = a.packed + wave * 4096 + lane * 16;
-    p.lds = lds;
-    p.lds_addr = (unsigned)(size_t)(lds_ptr_t)lds;
-    p.wave_off = wave * 4096;
-    p.lane16 = lane * 16;
-    p.n_stages = a.n_stages;
-    p.issue_src = 0;
-    p.issue_slot = 0;
-    p.next_read_slot = 0;
-    p.read_off = 0;
-    // biases: n_bias_tiles x 32 floats behind the ring
-    const float* bsrc = reinterpret_cast<const float*>(a.packed + (size_t)a.n_stages * STAGE_BYTES);
-    float* bdst = reinterpret_cast<float*>(lds + RING_BYTES);
-    for (int i = threadIdx.x; i < a.n_bias_tiles * 32; i += MLP_THREADS) bdst[i] = bsrc[i];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PREFETCH; ++i) p.issue();
-    p.advance();   // stage 0 ready
-}
-
-// ------------------------------------------------------------------------------------------
-// encodings, computed by the lane for ITS k-slots (mlp_layout.h)
-// ------------------------------------------------------------------------------------------
-template <bool FAST>
-__device__ __forceinline__ void sincos_any(float x, float& s, float& c) {
-    if (FAST) {
-        // v_sin/v_cos take revolutions and need |x| <= 256: reduce with v_fract first
-        const float r = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
-        s = __builtin_amdgcn_sinf(r);
-        c = __builtin_amdgcn_cosf(r);
-    } else {
-        sincosf(x, &s, &c);
-    }
-}
-
-template <bool FAST>
-__device__ __forceinline__ void encode_point(float px, float py, float pz, int h, float (&v)[32]) {
-    const float sc = h ? 32.0f : 1.0f;   // upper lane half: frequencies 2^5 .. 2^9
-    const float p[3] = {px * sc, py * sc, pz * sc};
-#pragma unroll
-    for (int fl = 0; fl < 5; ++fl) {
-#pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
-            float s, c;
-            sincos_any<FAST>(p[c3] * (float)(1 << fl), s, c);   // exact: power-of-two scaling
-            v[(fl * 3 + c3) * 2 + 0] = s;
-            v[(fl * 3 + c3) * 2 + 1] = c;
-        }
-    }
-    v[30] = h ? pz : px;
-    v[31] = h ? 0.0f : py;
-}
-
-template <bool FAST>
-__device__ __forceinline__ void encode_view(float dx, float dy, float dz, int h, float (&v)[16]) {
-    const float sc = h ? 4.0f : 1.0f;    // upper lane half: frequencies 2^2, 2^3
-    const float p[3] = {dx * sc, dy * sc, dz * sc};
-#pragma unroll
-    for (int fl = 0; fl < 2; ++fl) {
-#pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
-            float s, c;
-            sincos_any<FAST>(p[c3] * (float)(1 << fl), s, c);
-            v[(fl * 3 + c3) * 2 + 0] = s;
-            v[(fl * 3 + c3) * 2 + 1] = c;
-        }
-    }
-    v[12] = h ? 0.0f : dx;
-    v[13] = h ? 0.0f : dy;
-    v[14] = h ? 0.0f : dz;
-    v[15] = 0.0f;
-}
-
-// Raw inputs of one sample: what has to come from memory before the encodings can be computed.
-// NERF_IN_POINTS is expressed as origin = point, direction = 0, z = 0 (o + 0*0 == o exactly).
-struct RawIn {
-    float o[3], d[3], v[3], z;
-};
-
-// Issue the loads for sample m (already clamped to < M).  Nothing is computed here, so the loads
-// can be issued a whole network pass before their values are needed.
-template <bool VD>
-__device__ __forceinline__ void fetch_raw(const MlpArgs& a, unsigned m, RawIn& r) {
-    const unsigned ray = m / (unsigned)a.S;
-    if (a.mode == NERF_IN_RAYS) {
-        const float* q = a.in0 + (size_t)ray * a.ray_cols;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { r.o[k] = q[k]; r.d[k] = q[3 + k]; }
-        if (VD) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) r.v[k] = q[8 + k];
-        }
-        r.z = a.in1[m];
-    } else {
-        const float* q = a.in0 + (size_t)m * 3;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { r.o[k] = q[k]; r.d[k] = 0.0f; }
-        if (VD) {
-            const float* vq = a.in1 + (size_t)ray * 3;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) r.v[k] = vq[k];
-        }
-        r.z = 0.0f;
-    }
-}
-
-template <bool VD, bool FAST>
-__device__ __forceinline__ void encode_raw(const RawIn& r, int h, float (&pe)[32], float (&vw)[16]) {
-    // pts = rays_o + rays_d * z (run_nerf.py:387): product and sum rounded separately
-    encode_point<FAST>(fadd(r.o[0], fmul(r.d[0], r.z)), fadd(r.o[1], fmul(r.d[1], r.z)),
-                       fadd(r.o[2], fmul(r.d[2], r.z)), h, pe);
-    if (VD) encode_view<FAST>(r.v[0], r.v[1], r.v[2], h, vw);
-}
-
-// NERF_IN_FEATURES: the caller supplies the encodings; pick this lane's k-slots out of the row.
-template <bool VD>
-__device__ __forceinline__ void load_features(const MlpArgs& a, unsigned m, int h, float (&pe)[32], float (&vw)[16]) {
-    const int ch = VD ? 90 : 63;
-    const float* f = a.in0 + (size_t)m * ch;
-#pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        const int i0 = pe_slot_feature(0, q), i1 = pe_slot_feature(1, q);
-        const int idx = h ? i1 : i0;
-        pe[q] = idx >= 0 ? f[idx] : 0.0f;
-    }
-    if (VD) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int i0 = view_slot_feature(0, q), i1 = view_slot_feature(1, q);
-            const int idx = h ? i1 : i0;
-            vw[q] = idx >= 0 ? f[63 + idx] : 0.0f;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// shared by both precisions: bias tile -> accumulator layout
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x16 bias_tile(const unsigned char* lds, int tile, int h) {
-    // accumulator register r holds output row (r & 3) + 8 (r >> 2) + 4 h
-    const f32x4* b = reinterpret_cast<const f32x4*>(lds + RING_BYTES + tile * BIAS_TILE_BYTES + h * 16);
-    f32x16 acc;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 q = b[g * 2];
-        acc[4 * g + 0] = q[0]; acc[4 * g + 1] = q[1]; acc[4 * g + 2] = q[2]; acc[4 * g + 3] = q[3];
-    }
-    return acc;
-}
 
 // ------------------------------------------------------------------------------------------
 // bf16 kernel: 2 column tiles (64 samples) per wave, software-pipelined by hand:
@@ -546,34 +290,6 @@ void mlp_bf16_kernel(MlpArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
 
-// ------------------------------------------------------------------------------------------
-// f32 kernel: exact float32 MFMA (k-ordered fmaf chain), 1 column tile (32 samples) per wave
-// ------------------------------------------------------------------------------------------
-template <int NF>
-__device__ __forceinline__ void mma_run_f32(Pipe& p, int pos, f32x16& acc, const float* b) {
-#pragma unroll
-    for (int g = 0; g < NF; ++g) {
-        p.tick(pos + g);
-        const f32x4 w = *reinterpret_cast<const f32x4*>(p.frag(pos + g));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], b[4 * g + j], acc, 0, 0, 0);
-    }
-}
-
-template <int NT, bool PE, int HT /*hidden input tiles*/, bool VW, bool RELU>
-__device__ __forceinline__ void layer_f32(Pipe& p, int& pos, int& btile, int h, const float (&pe)[32],
-                                          const float (&hin)[8][16], const float (&vw)[16], float (&hout)[8][16]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        f32x16 acc = bias_tile(p.lds, btile + t, h);
-        if (PE) { mma_run_f32<8>(p, pos, acc, &pe[0]); pos += 8; }
-        if (HT) { mma_run_f32<HT * 4>(p, pos, acc, &hin[0][0]); pos += HT * 4; }
-        if (VW) { mma_run_f32<4>(p, pos, acc, &vw[0]); pos += 4; }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) hout[t][e] = RELU ? fmaxf(acc[e], 0.0f) : acc[e];
-    }
-    btile += NT;
-}
 
 template <bool VD, int OUT_CH>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -653,13 +369,6 @@ void mlp_f32_kernel(MlpArgs a) {
 // ------------------------------------------------------------------------------------------
 // weight packer
 // ------------------------------------------------------------------------------------------
-struct PackArgs {
-    NetDesc net;
-    const float* t[24];
-    int bf16;
-    int total_frags;
-    unsigned char* out;
-};
 
 __device__ __forceinline__ const float* pack_row(const PackArgs& a, const LayerDesc& L, int tile, int r, bool bias, int& row) {
     row = -1;
@@ -682,6 +391,10 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int F = gid >> 6, lane = gid & 63;
     const int r = lane & 31, h = lane >> 5;
+    if (F >= a.total_frags && F < a.padded_frags) {
+        *reinterpret_cast<float4*>(a.out + (size_t)F * FRAG_BYTES + lane * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     if (F < a.total_frags) {
         int f = F, li = 0;
         for (; li < a.net.n_layers; ++li) {
@@ -698,6 +411,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
         float vals[8];
         for (int j = 0; j < n_el; ++j) {
             int col = -1;
+            bool extra = false;
             if (a.bf16) {
                 const int npe = L.has_pe ? 4 : 0, nh = L.hid_feats / 16;
                 if (g < npe) { const int ft = pe_slot_feature(h, 8 * g + j); col = ft < 0 ? -1 : L.pe_col + ft; }
@@ -709,7 +423,23 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
                 else if (g < npe + nh) {
                     const int gh = g - npe, T = gh >> 2, e = (gh & 3) * 4 + j;
                     col = L.hid_col + 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
-                } else { const int ft = view_slot_feature(h, 4 * (g - npe - nh) + j); col = ft < 0 ? -1 : L.view_col + ft; }
+                } else if (g < npe + nh + (L.has_view ? 4 : 0)) {
+                    const int ft = view_slot_feature(h, 4 * (g - npe - nh) + j); col = ft < 0 ? -1 : L.view_col + ft;
+                } else {
+                    const int e = (g - npe - nh - (L.has_view ? 4 : 0)) * 4 + j;
+                    col = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    extra = true;
+                }
+            }
+            if (L.trans) {
+                // transposed read: layer row -> tensor column, k index -> tensor row
+                if (extra) {
+                    const float* W2 = a.t[L.w2_idx];
+                    vals[j] = (row >= 0 && col < L.k_limit2) ? W2[(size_t)col * L.in_dim2 + row] : 0.0f;
+                } else {
+                    vals[j] = (W && col >= 0 && col < L.k_limit) ? W[(size_t)col * L.in_dim + L.row_off + row] : 0.0f;
+                }
+                continue;
             }
             vals[j] = (W && col >= 0) ? W[(size_t)row * L.in_dim + col] : 0.0f;
         }
@@ -724,7 +454,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
         }
     } else {
         // bias block: n_bias_tiles x 32 floats in natural row order
-        const int bi = gid - a.total_frags * 64;
+        const int bi = gid - a.padded_frags * 64;
         if (bi >= a.net.n_bias_tiles * 32) return;
         int t = bi >> 5, li = 0;
         const int rr = bi & 31;
@@ -734,7 +464,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
         }
         int row;
         const float* Bp = pack_row(a, a.net.layer[li], t, rr, true, row);
-        reinterpret_cast<float*>(a.out + (size_t)a.total_frags * FRAG_BYTES)[bi] = Bp ? Bp[row] : 0.0f;
+        reinterpret_cast<float*>(a.out + (size_t)a.padded_frags * FRAG_BYTES)[bi] = Bp ? Bp[row] : 0.0f;
     }
 }
 
@@ -772,16 +502,11 @@ __global__ void selftest_kernel(int* bad) {
     if (nbad) atomicAdd(bad, nbad);
 }
 
-static int cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
+int launch_pack(const PackArgs& a, hipStream_t stream) {
+    const int threads = a.padded_frags * 64 + a.net.n_bias_tiles * 32;
+    hipLaunchKernelGGL(pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, a);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
 }
 
 }  // namespace nerf
@@ -839,10 +564,8 @@ extern "C" int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs,
     for (int i = 0; i < n_t; ++i)
         if (use_viewdirs || (i != 16 && i != 17)) NERF_REQUIRE(a.t[i], "nerf_mlp_pack: tensor %d is null", i);
     a.out = static_cast<unsigned char*>(packed_out);
-    const int threads = a.total_frags * 64 + a.net.n_bias_tiles * 32;
-    hipLaunchKernelGGL(pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, as_stream(stream), a);
-    NERF_LAUNCH_CHECK();
-    return NERF_OK;
+    a.padded_frags = a.total_frags;
+    return launch_pack(a, as_stream(stream));
 }
 
 extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int output_ch, int input_mode,

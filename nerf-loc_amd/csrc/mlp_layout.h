@@ -48,6 +48,12 @@ struct LayerDesc {
     int w2_idx, b2_idx;      // second tensor (alpha_linear for LK_FEATURE_ALPHA), else -1
     int in_dim;      // columns of the weight tensor
     int pe_col, hid_col, view_col;   // first column of each k part in the weight tensor
+    // Backward (input-gradient) layers use the TRANSPOSE of a weight tensor: output row r of the layer is
+    // column row_off + r of the tensor, k index c is its row c (valid for c < k_limit, zero beyond).
+    int trans, row_off, k_limit;
+    // optional extra k part of `extra_frags` float32 fragments taken from the transposed tensor w2_idx
+    // (row stride in_dim2, rows c < k_limit2): the density head joining the feature head's input gradient
+    int extra_frags, in_dim2, k_limit2;
 };
 
 struct NetDesc {
@@ -60,7 +66,7 @@ __host__ __device__ constexpr int ksteps_bf16(const LayerDesc& L) {
     return (L.has_pe ? 4 : 0) + L.hid_feats / 16 + (L.has_view ? 2 : 0);
 }
 __host__ __device__ constexpr int frags_f32(const LayerDesc& L) {
-    return (L.has_pe ? 8 : 0) + L.hid_feats / 8 + (L.has_view ? 4 : 0);
+    return (L.has_pe ? 8 : 0) + L.hid_feats / 8 + (L.has_view ? 4 : 0) + L.extra_frags;
 }
 __host__ __device__ constexpr int frags_per_tile(const LayerDesc& L, int prec_bf16) {
     return prec_bf16 ? ksteps_bf16(L) : frags_f32(L);
@@ -114,6 +120,33 @@ inline NetDesc make_net_desc(bool use_viewdirs, int output_ch) {
     n.n_bias_tiles = bt;
     return n;
 }
+
+// Input-gradient chain of the view-dependent network, float32 only.  Layers in execution order:
+//   rgb_linear^T (3 -> 128), views_linears.0^T restricted to the feature columns (128 -> 256),
+//   feature_linear^T plus alpha_linear^T (256 + 1 -> 256), then pts_linears 7..1 transposed
+//   (layer 5: only the 256 hidden columns, the encoded-input columns have no leaves behind them).
+inline NetDesc make_backward_desc() {
+    NetDesc n{};
+    int li = 0;
+    auto add = [&](int tiles, int out_dim, int kfeats, int w_idx, int in_dim, int row_off, int k_limit) -> LayerDesc& {
+        LayerDesc L{};
+        L.kind = LK_HIDDEN; L.n_tiles = tiles; L.out_dim = out_dim; L.hid_feats = kfeats;
+        L.w_idx = w_idx; L.b_idx = -1; L.w2_idx = L.b2_idx = -1; L.in_dim = in_dim;
+        L.trans = 1; L.row_off = row_off; L.k_limit = k_limit;
+        n.layer[li] = L;
+        return n.layer[li++];
+    };
+    add(4, 128, 8, 22, 128, 0, 3);                 // d(view hidden) = rgb_linear.weight^T d(rgb)
+    add(8, 256, 128, 16, 283, 0, 128);             // d(feature) = views_linears.0.weight[:, :256]^T d(view hidden)
+    LayerDesc& fa = add(8, 256, 256, 18, 256, 0, 256);   // d(h8) = feature^T d(feature) + alpha^T d(sigma)
+    fa.extra_frags = 1; fa.w2_idx = 20; fa.in_dim2 = 256; fa.k_limit2 = 1;
+    for (int i = 7; i >= 1; --i) add(8, 256, 256, 2 * i, i == 5 ? 319 : 256, i == 5 ? 63 : 0, 256);
+    n.n_layers = li;
+    n.n_bias_tiles = 0;
+    return n;
+}
+constexpr int FRAGS_BWD_F32 = 4 * 1 + 8 * 16 + 8 * 33 + 7 * 8 * 32;                  // 2188
+constexpr int FRAGS_BWD_F32_PADDED = (FRAGS_BWD_F32 + STAGE_FRAGS - 1) / STAGE_FRAGS * STAGE_FRAGS;   // 2192
 
 inline int total_frags(const NetDesc& n, int prec_bf16) {
     int t = 0;

@@ -1,0 +1,503 @@
+// Training kernels of the view-dependent NeRF network (float32, exact MFMA): the forward pass that
+// keeps its activations, the input-gradient chain, and the weight-gradient reductions.
+//
+// The reference trains through PyTorch autograd (run_nerf.py:770-796: loss.backward() over
+// NeRF.forward, run_nerf_helpers.py:96-119); nothing below has a line-by-line counterpart there.
+// What autograd would compute for the 24 parameter tensors is produced by three kinds of launches:
+//
+//   forward (mlp_f32_train_kernel)   the inference kernel's layer loop with a per-tile hook that stores
+//        every layer input a weight gradient needs ("tape", sample-major rows):
+//        enc(x) [M,64], enc(d) [M,32] (kernel k-slot order), h1..h8 [M,256], feature [M,256], view hidden [M,128]
+//   input gradients (mlp_dgrad_f32_kernel)   the same register-resident chain run on the TRANSPOSED
+//        weights (packed by the same packer, mlp_layout.h make_backward_desc): the gradient tile of one
+//        layer is the MFMA B operand of the next; ReLU masks come from the tape; every pre-activation
+//        gradient is stored ("gradient tape": dz1..dz8 [M,256], d feature [M,256], d view hidden [M,128])
+//   weight gradients (wgrad_kernel)   dW[out, in] = sum_m G[m, out] X[m, in]: samples are the MFMA k
+//        dimension, a workgroup owns a contiguous sample range and the full 256 x K tile in registers,
+//        partial tiles go to a workspace and a second kernel adds them in a fixed order (deterministic).
+//
+// Bounds: forward and input gradients MFMA (1.19 and 1.11 MFLOP/sample); weight gradients MFMA with
+// 2 KB/sample/layer of tape traffic (HBM-balanced at float32).
+#include "mlp_device.h"
+
+namespace nerf {
+
+constexpr int TAPE_PE = 64, TAPE_VW = 32;
+constexpr int TAPE_FLOATS = TAPE_PE + TAPE_VW + 8 * 256 + 256 + 128;   // 2528 per sample
+constexpr int GTAPE_FLOATS = 8 * 256 + 256 + 128;                      // 2432 per sample
+constexpr int WG_MAX_PARTS = 256;                                      // workgroups of a weight-gradient launch
+
+struct TapePtrs {
+    float* pe; float* vw; float* h[8]; float* feat; float* hv;
+};
+struct GTapePtrs {
+    float* dz[8]; float* dfeat; float* dzv;
+};
+
+static TapePtrs tape_ptrs(float* base, long long M) {
+    TapePtrs t;
+    size_t o = 0;
+    t.pe = base + o; o += (size_t)M * TAPE_PE;
+    t.vw = base + o; o += (size_t)M * TAPE_VW;
+    for (int i = 0; i < 8; ++i) { t.h[i] = base + o; o += (size_t)M * 256; }
+    t.feat = base + o; o += (size_t)M * 256;
+    t.hv = base + o;
+    return t;
+}
+static GTapePtrs gtape_ptrs(float* base, long long M) {
+    GTapePtrs t;
+    size_t o = 0;
+    for (int i = 0; i < 8; ++i) { t.dz[i] = base + o; o += (size_t)M * 256; }
+    t.dfeat = base + o; o += (size_t)M * 256;
+    t.dzv = base + o;
+    return t;
+}
+
+// per-tile hooks -----------------------------------------------------------------------------
+// Accumulator register 4 g + k of tile t holds feature 32 t + 8 g + 4 h + k of the lane's sample: four
+// 16-byte pieces per tile and lane in a sample-major row.
+struct SaveTile {
+    float* row;      // dst + m * ld + 4 h  (nullptr: sample beyond M, nothing is stored)
+    __device__ __forceinline__ void operator()(int t, float (&v)[16]) const {
+        if (!row) return;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(row + 32 * t + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    }
+};
+
+// gradient tile: zero where the forward activation was not positive (ReLU), then store
+template <bool MASK>
+struct MaskSaveTile {
+    const float* act;   // forward activation row of a valid sample (+ 4 h)
+    float* row;         // destination row (+ 4 h) or nullptr
+    __device__ __forceinline__ void operator()(int t, float (&v)[16]) const {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (MASK) {
+                const float4 a = *reinterpret_cast<const float4*>(act + 32 * t + 8 * g);
+                v[4 * g + 0] = a.x > 0.0f ? v[4 * g + 0] : 0.0f;
+                v[4 * g + 1] = a.y > 0.0f ? v[4 * g + 1] : 0.0f;
+                v[4 * g + 2] = a.z > 0.0f ? v[4 * g + 2] : 0.0f;
+                v[4 * g + 3] = a.w > 0.0f ? v[4 * g + 3] : 0.0f;
+            }
+            if (row) *reinterpret_cast<float4*>(row + 32 * t + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// forward with tape
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mlp_f32_train_kernel(MlpArgs a, TapePtrs tp) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    Pipe p;
+    pipe_start(p, a, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const long long n_tiles = (a.M + 127) / 128;
+    const bool feat_mode = a.mode == NERF_IN_FEATURES;
+    const unsigned Mu = (unsigned)a.M;
+
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const unsigned m = (unsigned)tile * 128u + wave * 32 + c;
+        const bool valid = m < Mu;
+        const unsigned mc = valid ? m : Mu - 1;
+        float pe[32], vw[16];
+        if (feat_mode) {
+            load_features<true>(a, mc, h, pe, vw);
+        } else {
+            RawIn cur;
+            fetch_raw<true>(a, mc, cur);
+            encode_raw<true, false>(cur, h, pe, vw);
+        }
+        if (valid) {
+            float4* q = reinterpret_cast<float4*>(tp.pe + (size_t)m * TAPE_PE + 32 * h);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) q[g] = make_float4(pe[4 * g], pe[4 * g + 1], pe[4 * g + 2], pe[4 * g + 3]);
+            float4* qv = reinterpret_cast<float4*>(tp.vw + (size_t)m * TAPE_VW + 16 * h);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) qv[g] = make_float4(vw[4 * g], vw[4 * g + 1], vw[4 * g + 2], vw[4 * g + 3]);
+        }
+        auto save256 = [&](float* base) { return SaveTile{valid ? base + (size_t)m * 256 + 4 * h : nullptr}; };
+
+        float A[8][16], B[8][16];
+        int pos = 0, bt = 0;
+        layer_f32<8, true, 0, false, true>(p, pos, bt, h, pe, A, vw, A, save256(tp.h[0]));
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, A, vw, B, save256(tp.h[1]));
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, B, vw, A, save256(tp.h[2]));
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, A, vw, B, save256(tp.h[3]));
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, B, vw, A, save256(tp.h[4]));
+        layer_f32<8, true, 8, false, true>(p, pos, bt, h, pe, A, vw, B, save256(tp.h[5]));
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, B, vw, A, save256(tp.h[6]));
+        layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, A, vw, B, save256(tp.h[7]));
+        layer_f32<8, false, 8, false, false>(p, pos, bt, h, pe, B, vw, A, save256(tp.feat));
+        float o3;
+        {
+            f32x16 acc = bias_tile(p.lds, bt, h);
+            mma_run_f32<32>(p, pos, acc, &B[0][0]);
+            pos += 32; bt += 1;
+            o3 = acc[3];
+        }
+        layer_f32<4, false, 8, true, true>(p, pos, bt, h, pe, A, vw, B,
+                                           SaveTile{valid ? tp.hv + (size_t)m * 128 + 4 * h : nullptr});
+        f32x16 acc = bias_tile(p.lds, bt, h);
+        mma_run_f32<16>(p, pos, acc, &B[0][0]);
+        if (valid && h == 0) *reinterpret_cast<float4*>(a.out + (size_t)m * 4) = make_float4(acc[0], acc[1], acc[2], o3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// input-gradient chain
+// ------------------------------------------------------------------------------------------
+struct DgradArgs {
+    const unsigned char* packed;   // transposed-weight fragment stream (make_backward_desc)
+    int n_stages;
+    long long M;
+    const float* d_raw;            // [M,4]: gradient of the loss w.r.t. raw (rgb pre-sigmoid, sigma pre-relu)
+    TapePtrs tp;
+    GTapePtrs gt;
+};
+
+template <int NT, int NF, bool EXTRA, class Hook>
+__device__ __forceinline__ void layer_bwd_f32(Pipe& p, int& pos, const float* hin, const float (&ex)[4],
+                                              float (&hout)[8][16], Hook hook) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        mma_run_f32<NF>(p, pos, acc, hin);
+        pos += NF;
+        if (EXTRA) { mma_run_f32<1>(p, pos, acc, &ex[0]); pos += 1; }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hout[t][e] = acc[e];
+        hook(t, hout[t]);
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mlp_dgrad_f32_kernel(DgradArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    Pipe p;
+    {
+        MlpArgs ma{};
+        ma.packed = a.packed; ma.n_stages = a.n_stages; ma.n_bias_tiles = 0;
+        pipe_start(p, ma, lds);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const long long n_tiles = (a.M + 127) / 128;
+    const unsigned Mu = (unsigned)a.M;
+
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const unsigned m = (unsigned)tile * 128u + wave * 32 + c;
+        const bool valid = m < Mu;
+        const unsigned mc = valid ? m : Mu - 1;
+        const float4 dr = *reinterpret_cast<const float4*>(a.d_raw + (size_t)mc * 4);
+        // k slot (j, h) of a one-fragment part is input index j + 4 h (mlp_layout.h, hidden convention, tile 0)
+        const float drgb[4] = {h ? 0.0f : dr.x, h ? 0.0f : dr.y, h ? 0.0f : dr.z, 0.0f};
+        const float dsig[4] = {h ? 0.0f : dr.w, 0.0f, 0.0f, 0.0f};
+        const float none[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto rows = [&](const float* act, float* dst, int ld) {
+            return MaskSaveTile<true>{act + (size_t)mc * ld + 4 * h, valid ? dst + (size_t)m * ld + 4 * h : nullptr};
+        };
+        float A[8][16], B[8][16];
+        int pos = 0;
+        layer_bwd_f32<4, 1, false>(p, pos, &drgb[0], none, B, rows(a.tp.hv, a.gt.dzv, 128));
+        layer_bwd_f32<8, 16, false>(p, pos, &B[0][0], none, A,
+                                    MaskSaveTile<false>{nullptr, valid ? a.gt.dfeat + (size_t)m * 256 + 4 * h : nullptr});
+        layer_bwd_f32<8, 32, true>(p, pos, &A[0][0], dsig, B, rows(a.tp.h[7], a.gt.dz[7], 256));
+        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[6], a.gt.dz[6], 256));   // pts_linears.7^T
+        layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(a.tp.h[5], a.gt.dz[5], 256));   // .6
+        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[4], a.gt.dz[4], 256));   // .5 (hidden columns)
+        layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(a.tp.h[3], a.gt.dz[3], 256));   // .4
+        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[2], a.gt.dz[2], 256));   // .3
+        layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(a.tp.h[1], a.gt.dz[1], 256));   // .2
+        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[0], a.gt.dz[0], 256));   // .1
+        // zero fragments that pad the stream to a whole stage
+#pragma unroll
+        for (int g = 0; g < FRAGS_BWD_F32_PADDED - FRAGS_BWD_F32; ++g) p.tick(pos + g);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradients
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* G; int ldg; int N;      // gradient rows   [M, ldg], N <= 256 output features used
+    const float* X; int ldx; int K;      // layer inputs    [M, ldx], K <= 32 CT input features used
+    long long M;
+    long long chunk;                     // samples per workgroup (even)
+    float* part;                         // [grid][256][32 CT]
+    float* bpart;                        // [grid][256] column sums of G, or nullptr
+};
+
+// v_mfma_f32_32x32x2_f32 with i = output feature, j = input feature, k = sample: lane (r, h) feeds
+// G[m + h][32 rt + r] and X[m + h][32 ct + r].  Wave w owns output rows 64 w .. 64 w + 63.
+template <int CT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void wgrad_kernel(WgradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = 64 * wave;
+    float* part = a.part + (size_t)blockIdx.x * 256 * (32 * CT);
+    if (row0 >= a.N) return;                       // whole wave: these rows are never read back
+    const bool two = row0 + 32 < a.N;              // second row tile in use
+    const long long m0 = (long long)blockIdx.x * a.chunk;
+    const long long m1 = m0 + a.chunk < a.M ? m0 + a.chunk : a.M;
+
+    f32x16 acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][ct][e] = 0.0f;
+    float bs0 = 0.0f, bs1 = 0.0f;
+
+    const bool g0ok = row0 + r < a.N, g1ok = row0 + 32 + r < a.N;
+    constexpr int DEPTH = 4;                       // k-steps of operands in flight
+    float ga[DEPTH][2], xb[DEPTH][CT];
+    auto load = [&](int slot, long long m) {
+        const long long mm = m + h;
+        const bool ok = mm < m1;
+        const float* gp = a.G + (size_t)(ok ? mm : m0) * a.ldg + row0 + r;
+        const float* xp = a.X + (size_t)(ok ? mm : m0) * a.ldx + r;
+        ga[slot][0] = (ok && g0ok) ? gp[0] : 0.0f;
+        ga[slot][1] = (ok && g1ok) ? gp[32] : 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) xb[slot][ct] = (ok && 32 * ct + r < a.K) ? xp[32 * ct] : 0.0f;
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) load(d, m0 + 2 * d);
+    for (long long mb = m0; mb < m1; mb += 2 * DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const long long m = mb + 2 * d;
+            load((d + DEPTH - 1) % DEPTH, m + 2 * (DEPTH - 1));      // rows beyond m1 load zeros
+            const float g0 = ga[d][0], g1 = ga[d][1];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, xb[d][ct], acc[0][ct], 0, 0, 0);
+                if (two) acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, xb[d][ct], acc[1][ct], 0, 0, 0);
+            }
+            bs0 += g0; bs1 += g1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i == 1 && !two) break;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                part[(size_t)row * (32 * CT) + 32 * ct + r] = acc[i][ct][e];
+            }
+    }
+    if (a.bpart) {
+        bs0 += __shfl_xor(bs0, 32, WAVE);
+        bs1 += __shfl_xor(bs1, 32, WAVE);
+        if (h == 0) {
+            a.bpart[(size_t)blockIdx.x * 256 + row0 + r] = bs0;
+            a.bpart[(size_t)blockIdx.x * 256 + row0 + 32 + r] = two ? bs1 : 0.0f;
+        }
+    }
+}
+
+// Heads with 1 or 3 outputs (alpha_linear, rgb_linear): G is a column range of d_raw [M,4].  One thread
+// per input feature, samples of the block's range in sequence; X rows are read coalesced, G by broadcast.
+struct WsmallArgs {
+    const float* d_raw; int c0, N;       // output o <-> d_raw column c0 + o, N <= 3
+    const float* X; int K;               // [M, K], K = blockDim.x
+    long long M, chunk;
+    float* part;                         // [grid][4][K]
+    float* bpart;                        // [grid][4]
+};
+__global__ void wgrad_small_kernel(WsmallArgs a) {
+    const int k = threadIdx.x;
+    const long long m0 = (long long)blockIdx.x * a.chunk;
+    const long long m1 = m0 + a.chunk < a.M ? m0 + a.chunk : a.M;
+    float s[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
+    for (long long m = m0; m < m1; ++m) {
+        const float x = a.X[(size_t)m * a.K + k];
+        const float4 g = *reinterpret_cast<const float4*>(a.d_raw + (size_t)m * 4);
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+            if (o < a.N) { s[o] = fmaf(gv[a.c0 + o], x, s[o]); b[o] += gv[a.c0 + o]; }
+    }
+    for (int o = 0; o < a.N; ++o) a.part[((size_t)blockIdx.x * 4 + o) * a.K + k] = s[o];
+    if (k == 0) for (int o = 0; o < a.N; ++o) a.bpart[(size_t)blockIdx.x * 4 + o] = b[o];
+}
+
+// dst[row * ld + col_off + map(col)] = sum over parts, in part order.  map: 0 identity, 1 encoded-point
+// k-slot -> reference column, 2 encoded-view k-slot -> reference column (slots without a feature are dropped).
+struct ReduceArgs {
+    const float* part; int n_parts; int prow; int pcol;   // [n_parts][prow][pcol]
+    int N, K;                                             // rows / columns to emit
+    float* dst; int ld; int col_off; int map;
+};
+__global__ void wgrad_reduce_kernel(ReduceArgs a) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (col >= a.K || row >= a.N) return;
+    int dc = col;
+    if (a.map == 1) dc = pe_slot_feature(col >> 5, col & 31);
+    else if (a.map == 2) dc = view_slot_feature(col >> 4, col & 15);
+    if (dc < 0) return;
+    const float* p = a.part + (size_t)row * a.pcol + col;
+    const size_t stride = (size_t)a.prow * a.pcol;
+    float s = 0.0f;
+    for (int i = 0; i < a.n_parts; ++i) s += p[i * stride];
+    a.dst[(size_t)row * a.ld + a.col_off + dc] = s;
+}
+
+static int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K, long long M,
+                        float* ws, float* dW, int ld, int col_off, int map, float* db, hipStream_t st) {
+    const int ct = (K + 31) / 32;
+    long long parts = (M + 511) / 512;             // at least 512 samples per workgroup
+    if (parts > WG_MAX_PARTS) parts = WG_MAX_PARTS;
+    if (parts > cu_count()) parts = cu_count();
+    if (parts < 1) parts = 1;
+    long long chunk = (M + parts - 1) / parts;
+    chunk += chunk & 1;
+    parts = (M + chunk - 1) / chunk;
+    WgradArgs a{G, ldg, N, X, ldx, K, M, chunk, ws, db ? ws + (size_t)WG_MAX_PARTS * 256 * 256 : nullptr};
+    const int ctp = ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : 8;
+    dim3 grid((unsigned)parts), block(256);
+    switch (ctp) {
+        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(wgrad_kernel<8>, grid, block, 0, st, a); break;
+    }
+    NERF_LAUNCH_CHECK();
+    ReduceArgs r{ws, (int)parts, 256, 32 * ctp, N, map == 0 ? K : 32 * ct, dW, ld, col_off, map};
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r.K + 63) / 64, N), dim3(64), 0, st, r);
+    NERF_LAUNCH_CHECK();
+    if (db) {
+        ReduceArgs rb{a.bpart, (int)parts, 1, 256, 1, N, db, N, 0, 0};
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N + 63) / 64, 1), dim3(64), 0, st, rb);
+        NERF_LAUNCH_CHECK();
+    }
+    return NERF_OK;
+}
+
+static int launch_wgrad_small(const float* d_raw, int c0, int N, const float* X, int K, long long M, float* ws,
+                              float* dW, float* db, hipStream_t st) {
+    long long parts = (M + 255) / 256;
+    if (parts > 1024) parts = 1024;
+    const long long chunk = (M + parts - 1) / parts;
+    parts = (M + chunk - 1) / chunk;
+    WsmallArgs a{d_raw, c0, N, X, K, M, chunk, ws, ws + (size_t)1024 * 4 * 256};
+    hipLaunchKernelGGL(wgrad_small_kernel, dim3((unsigned)parts), dim3(K), 0, st, a);
+    NERF_LAUNCH_CHECK();
+    ReduceArgs r{ws, (int)parts, 4, K, N, K, dW, K, 0, 0};
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K + 63) / 64, N), dim3(64), 0, st, r);
+    NERF_LAUNCH_CHECK();
+    ReduceArgs rb{a.bpart, (int)parts, 1, 4, 1, N, db, N, 0, 0};
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1, 1), dim3(64), 0, st, rb);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+extern "C" size_t nerf_train_tape_bytes(long long M) { return M < 0 ? 0 : (size_t)M * TAPE_FLOATS * sizeof(float); }
+extern "C" size_t nerf_train_grad_tape_bytes(long long M) { return M < 0 ? 0 : (size_t)M * GTAPE_FLOATS * sizeof(float); }
+extern "C" size_t nerf_train_workspace_bytes(void) {
+    return ((size_t)WG_MAX_PARTS * 256 * 256 + (size_t)WG_MAX_PARTS * 256) * sizeof(float);
+}
+extern "C" size_t nerf_mlp_backward_packed_bytes(void) { return (size_t)FRAGS_BWD_F32_PADDED * FRAG_BYTES; }
+
+extern "C" int nerf_mlp_pack_backward(const float* const* tensors_host, void* packed_out, void* stream) {
+    NERF_REQUIRE(tensors_host && packed_out, "nerf_mlp_pack_backward: null pointer");
+    PackArgs a;
+    a.net = make_backward_desc();
+    a.bf16 = 0;
+    a.total_frags = total_frags(a.net, 0);
+    a.padded_frags = FRAGS_BWD_F32_PADDED;
+    NERF_REQUIRE(a.total_frags == FRAGS_BWD_F32, "nerf_mlp_pack_backward: internal layout mismatch");
+    for (int i = 0; i < 24; ++i) {
+        a.t[i] = tensors_host[i];
+        if (i % 2 == 0) NERF_REQUIRE(a.t[i], "nerf_mlp_pack_backward: weight tensor %d is null", i);
+    }
+    a.out = static_cast<unsigned char*>(packed_out);
+    return launch_pack(a, as_stream(stream));
+}
+
+extern "C" int nerf_mlp_forward_train(const void* packed, int input_mode, const float* in0, const float* in1, int R,
+                                      int S, int ray_cols, float* raw_out, float* tape, void* stream) {
+    NERF_REQUIRE(packed && in0 && raw_out && tape, "nerf_mlp_forward_train: null pointer");
+    NERF_REQUIRE(R >= 0 && S >= 1, "nerf_mlp_forward_train: bad shape R=%d S=%d", R, S);
+    switch (input_mode) {
+        case NERF_IN_FEATURES: NERF_REQUIRE(S == 1, "nerf_mlp_forward_train: feature input is flat (S = 1)"); break;
+        case NERF_IN_POINTS: NERF_REQUIRE(in1, "nerf_mlp_forward_train: view directions missing"); break;
+        case NERF_IN_RAYS:
+            NERF_REQUIRE(in1, "nerf_mlp_forward_train: z_vals missing");
+            NERF_REQUIRE(ray_cols >= 11, "nerf_mlp_forward_train: rays need 11 columns, got %d", ray_cols);
+            break;
+        default: NERF_REQUIRE(false, "nerf_mlp_forward_train: unknown input mode %d", input_mode);
+    }
+    NERF_REQUIRE(((uintptr_t)raw_out & 15) == 0 && ((uintptr_t)tape & 15) == 0 && ((uintptr_t)packed & 15) == 0,
+                 "nerf_mlp_forward_train: buffers must be 16-byte aligned");
+    const long long M = (long long)R * S;
+    if (M == 0) return NERF_OK;
+    NERF_REQUIRE(M < (1ll << 31) - 512, "nerf_mlp_forward_train: at most 2^31 - 512 samples per launch, got %lld", M);
+    MlpArgs a;
+    a.packed = static_cast<const unsigned char*>(packed);
+    a.n_stages = FRAGS_F32_VD / STAGE_FRAGS;
+    a.n_bias_tiles = BIAS_TILES_VD;
+    a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
+    const long long n_tiles = (M + 127) / 128;
+    const int grid = (int)(n_tiles < cu_count() ? n_tiles : cu_count());
+    hipLaunchKernelGGL(mlp_f32_train_kernel, dim3(grid), dim3(MLP_THREADS), 0, as_stream(stream), a, tape_ptrs(tape, M));
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+}
+
+extern "C" int nerf_mlp_backward(const void* packed_bwd, const float* d_raw, long long M, const float* tape,
+                                 float* grad_tape, float* workspace, size_t workspace_bytes,
+                                 float* const* grads_host, void* stream) {
+    NERF_REQUIRE(packed_bwd && d_raw && tape && grad_tape && workspace && grads_host, "nerf_mlp_backward: null pointer");
+    NERF_REQUIRE(workspace_bytes >= nerf_train_workspace_bytes(), "nerf_mlp_backward: workspace of %zu bytes, %zu needed",
+                 workspace_bytes, nerf_train_workspace_bytes());
+    NERF_REQUIRE(((uintptr_t)d_raw & 15) == 0 && ((uintptr_t)tape & 15) == 0 && ((uintptr_t)grad_tape & 15) == 0,
+                 "nerf_mlp_backward: buffers must be 16-byte aligned");
+    NERF_REQUIRE(M >= 1 && M < (1ll << 31) - 512, "nerf_mlp_backward: bad sample count %lld", M);
+    for (int i = 0; i < 24; ++i) NERF_REQUIRE(grads_host[i], "nerf_mlp_backward: gradient tensor %d is null", i);
+    hipStream_t st = as_stream(stream);
+    const TapePtrs tp = tape_ptrs(const_cast<float*>(tape), M);
+    const GTapePtrs gt = gtape_ptrs(grad_tape, M);
+    DgradArgs d;
+    d.packed = static_cast<const unsigned char*>(packed_bwd);
+    d.n_stages = FRAGS_BWD_F32_PADDED / STAGE_FRAGS;
+    d.M = M; d.d_raw = d_raw; d.tp = tp; d.gt = gt;
+    const long long n_tiles = (M + 127) / 128;
+    const int grid = (int)(n_tiles < cu_count() ? n_tiles : cu_count());
+    hipLaunchKernelGGL(mlp_dgrad_f32_kernel, dim3(grid), dim3(MLP_THREADS), 0, st, d);
+    NERF_LAUNCH_CHECK();
+
+    float* const* g = grads_host;   // state_dict order: pts_linears.i -> 2i, 2i+1; views 16,17; feature 18,19; alpha 20,21; rgb 22,23
+    int rc;
+#define NERF_TRY(x) do { rc = (x); if (rc != NERF_OK) return rc; } while (0)
+    NERF_TRY(launch_wgrad(gt.dz[0], 256, 256, tp.pe, TAPE_PE, 64, M, workspace, g[0], 63, 0, 1, g[1], st));
+    for (int i = 1; i < 8; ++i) {
+        const int ld = i == 5 ? 319 : 256, off = i == 5 ? 63 : 0;
+        NERF_TRY(launch_wgrad(gt.dz[i], 256, 256, tp.h[i - 1], 256, 256, M, workspace, g[2 * i], ld, off, 0, g[2 * i + 1], st));
+        if (i == 5) NERF_TRY(launch_wgrad(gt.dz[5], 256, 256, tp.pe, TAPE_PE, 64, M, workspace, g[10], 319, 0, 1, nullptr, st));
+    }
+    NERF_TRY(launch_wgrad(gt.dfeat, 256, 256, tp.h[7], 256, 256, M, workspace, g[18], 256, 0, 0, g[19], st));
+    NERF_TRY(launch_wgrad(gt.dzv, 128, 128, tp.feat, 256, 256, M, workspace, g[16], 283, 0, 0, g[17], st));
+    NERF_TRY(launch_wgrad(gt.dzv, 128, 128, tp.vw, TAPE_VW, 32, M, workspace, g[16], 283, 256, 2, nullptr, st));
+    NERF_TRY(launch_wgrad_small(d_raw, 3, 1, tp.h[7], 256, M, workspace, g[20], g[21], st));
+    NERF_TRY(launch_wgrad_small(d_raw, 0, 3, tp.hv, 128, M, workspace, g[22], g[23], st));
+#undef NERF_TRY
+    return NERF_OK;
+}

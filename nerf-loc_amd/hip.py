@@ -45,6 +45,19 @@ _SIGNATURES = {
                                        ctypes.c_int, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p, _c_float_p,
                                        _c_float_p, ctypes.c_void_p]),
+    "nerf_raw2outputs_backward": (ctypes.c_int, [_c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int,
+                                                 _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p,
+                                                 _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "nerf_train_tape_bytes": (ctypes.c_size_t, [ctypes.c_longlong]),
+    "nerf_train_grad_tape_bytes": (ctypes.c_size_t, [ctypes.c_longlong]),
+    "nerf_train_workspace_bytes": (ctypes.c_size_t, []),
+    "nerf_mlp_forward_train": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "nerf_mlp_backward_packed_bytes": (ctypes.c_size_t, []),
+    "nerf_mlp_pack_backward": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p]),
+    "nerf_mlp_backward": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, ctypes.c_longlong, _c_float_p, _c_float_p,
+                                         _c_float_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
+                                         ctypes.c_void_p]),
 }
 
 _lib = None
@@ -275,3 +288,66 @@ def sample_pdf(bins, weights, u, bins_are_z=False, z_vals=None, want_samples=Tru
                                      n_z, _ptr(zs), None if inds is None else ctypes.c_void_p(inds.data_ptr()),
                                      _ptr(zsorted), _ptr(std), _stream(bins)), "nerf_sample_pdf")
     return zs, inds, zsorted, std
+
+
+# --------------------------------------------------------------------------- training
+def raw2outputs_backward(raw, z, d, d_stride, noise, white_bkgd, g_rgb=None, g_disp=None, g_acc=None, g_depth=None):
+    """dL/draw [R,S,ch] from the upstream gradients of the maps (None = zero)."""
+    raw, z = _f32(raw, "raw"), _f32(z, "z_vals", raw.device)
+    R, S, ch = raw.shape
+    dev = raw.device
+    gs = [None if g is None else _f32(g, "upstream gradient", dev) for g in (g_rgb, g_disp, g_acc, g_depth)]
+    noise = _f32(noise, "noise", dev) if noise is not None else None
+    d_raw = torch.empty_like(raw)
+    with torch.cuda.device(dev):
+        _check(lib().nerf_raw2outputs_backward(_ptr(raw), ch, _ptr(z), ctypes.c_void_p(d.data_ptr()), int(d_stride),
+                                               _ptr(noise), R, S, int(bool(white_bkgd)), _ptr(gs[0]), _ptr(gs[1]),
+                                               _ptr(gs[2]), _ptr(gs[3]), _ptr(d_raw), _stream(raw)),
+               "nerf_raw2outputs_backward")
+    return d_raw
+
+
+def mlp_pack_backward(tensors):
+    dev = tensors[0].device
+    keep = [_f32(t.detach(), "weight %d" % i, dev) for i, t in enumerate(tensors)]
+    arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in keep])
+    packed = torch.empty((lib().nerf_mlp_backward_packed_bytes(),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().nerf_mlp_pack_backward(arr, ctypes.c_void_p(packed.data_ptr()), _stream(packed)),
+               "nerf_mlp_pack_backward")
+    return packed
+
+
+def mlp_forward_train(packed, mode, in0, in1, R, S, ray_cols=0):
+    """float32 forward that keeps its activations: returns (raw [R*S,4], tape)."""
+    in0 = _f32(in0, "mlp input")
+    in1 = _f32(in1, "mlp second input", in0.device) if in1 is not None else None
+    M = R * S
+    out = torch.empty((M, 4), dtype=torch.float32, device=in0.device)
+    tape = torch.empty((lib().nerf_train_tape_bytes(M) // 4,), dtype=torch.float32, device=in0.device)
+    with torch.cuda.device(in0.device):
+        _check(lib().nerf_mlp_forward_train(ctypes.c_void_p(packed.data_ptr()), mode, _ptr(in0), _ptr(in1), int(R),
+                                            int(S), int(ray_cols), _ptr(out), _ptr(tape), _stream(out)),
+               "nerf_mlp_forward_train")
+    return out, tape
+
+
+_WORKSPACE = {}
+
+
+def mlp_backward(packed_bwd, d_raw, tape, shapes):
+    """Gradients of the 24 parameter tensors (list in state_dict order, shaped like `shapes`)."""
+    d_raw = _f32(d_raw, "d_raw")
+    dev = d_raw.device
+    M = d_raw.numel() // 4
+    gtape = torch.empty((lib().nerf_train_grad_tape_bytes(M) // 4,), dtype=torch.float32, device=dev)
+    ws = _WORKSPACE.get(str(dev))
+    if ws is None:
+        ws = _WORKSPACE[str(dev)] = torch.empty((lib().nerf_train_workspace_bytes() // 4,), dtype=torch.float32,
+                                                device=dev)
+    grads = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    arr = (ctypes.c_void_p * 24)(*[g.data_ptr() for g in grads])
+    with torch.cuda.device(dev):
+        _check(lib().nerf_mlp_backward(ctypes.c_void_p(packed_bwd.data_ptr()), _ptr(d_raw), M, _ptr(tape), _ptr(gtape),
+                                       _ptr(ws), ws.numel() * 4, arr, _stream(d_raw)), "nerf_mlp_backward")
+    return grads

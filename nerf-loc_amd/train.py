@@ -1,29 +1,202 @@
-"""Differentiable entry points (training step of run_nerf.py:770-796).
+"""Differentiable entry points: what the training step of run_nerf.py:770-796
+needs from the render path (render(..., retraw=True) -> img2mse -> backward).
 
-The backward kernels are not built yet: any call that would need a gradient
-through the HIP ops raises instead of silently producing none.  Inference
-(torch.no_grad(), or networks whose parameters do not require grad) never
-reaches this module.
+The reference gets gradients from PyTorch autograd over eager ops.  Here two
+torch.autograd.Function nodes wrap hand-written HIP kernels:
+
+  _NetworkFn    NeRF.forward / run_network: float32 forward that keeps its
+                activations, then input-gradient chain + weight-gradient GEMMs
+                (gradients for the 24 parameter tensors; none for the inputs:
+                sample positions and view directions have no leaves behind them)
+  _CompositeFn  raw2outputs: closed-form backward of the alpha compositing
+
+Training always computes in float32 (like the reference), whatever the
+``precision`` attribute says about inference.  Only the view-dependent
+architecture (use_viewdirs=True, the one every config of the reference trains)
+is implemented; others raise NotImplementedError.  Nothing here falls back to
+autograd over torch ops.
 """
+import numpy as np
+import torch
+
+from . import hip
+
+_PARAM_ORDER = (["pts_linears.%d.%s" % (i, k) for i in range(8) for k in ("weight", "bias")] +
+                ["views_linears.0.weight", "views_linears.0.bias", "feature_linear.weight", "feature_linear.bias",
+                 "alpha_linear.weight", "alpha_linear.bias", "rgb_linear.weight", "rgb_linear.bias"])
 
 
-def _no_backward(what):
-    raise NotImplementedError(
-        what + ": gradients through the HIP kernels are not implemented yet; run under torch.no_grad() "
-        "or call .requires_grad_(False) on the network for inference")
+def _params(model):
+    if not (model.use_viewdirs and model.hip_supported()):
+        raise NotImplementedError("training kernels implement the view-dependent network only (use_viewdirs=True, "
+                                  "D=8, W=256, skips=[4], input_ch=63, input_ch_views=27)")
+    named = dict(model.named_parameters())
+    return [named[k] for k in _PARAM_ORDER]
 
 
+def _packed_backward(model, params):
+    """Transposed-weight stream for the input-gradient chain, cached per weight version."""
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    hit = model._pack_cache.get("bwd")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    packed = hip.mlp_pack_backward([p.detach() for p in params])
+    model._pack_cache["bwd"] = (key, packed)
+    return packed
+
+
+class _NetworkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, mode, in0, in1, R, S, ray_cols, *params):
+        packed = model.packed_weights(hip.PREC_F32)
+        raw, tape = hip.mlp_forward_train(packed, mode, in0, in1, R, S, ray_cols)
+        ctx.tape = tape
+        ctx.packed_bwd = _packed_backward(model, params)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        grads = hip.mlp_backward(ctx.packed_bwd, g_raw.contiguous(), ctx.tape, ctx.shapes)
+        ctx.tape = None
+        return (None,) * 7 + tuple(grads)
+
+
+class _CompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, z_vals, d, d_stride, noise, white_bkgd):
+        rgb, disp, acc, weights, depth = hip.raw2outputs(raw, z_vals, d, d_stride, noise, white_bkgd)
+        ctx.save_for_backward(raw, z_vals, d)
+        ctx.misc = (d_stride, noise, white_bkgd)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(weights)
+        return rgb, disp, acc, weights, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_weights, g_depth):
+        raw, z_vals, d = ctx.saved_tensors
+        d_stride, noise, white_bkgd = ctx.misc
+        d_raw = hip.raw2outputs_backward(raw, z_vals, d, d_stride, noise, white_bkgd, g_rgb, g_disp, g_acc, g_depth)
+        return d_raw, None, None, None, None, None
+
+
+def _no_input_grad(t, what):
+    if isinstance(t, torch.Tensor) and t.requires_grad:
+        raise NotImplementedError("%s requires grad: the HIP training kernels produce gradients for the network "
+                                  "parameters only (the reference never optimises rays or poses)" % what)
+
+
+# ---------------------------------------------------------------------------- entry points used by helpers / render
 def mlp_forward_autograd(model, x):
-    _no_backward("NeRF.forward")
+    """NeRF.forward on encoded features [..., 90] with parameter gradients."""
+    _no_input_grad(x, "the encoded network input")
+    params = _params(model)
+    flat = x.reshape(-1, x.shape[-1])[:, :90].contiguous().float()
+    out = _NetworkFn.apply(model, hip.IN_FEATURES, flat, None, flat.shape[0], 1, 0, *params)
+    return out.reshape(tuple(x.shape[:-1]) + (4,))
 
 
 def run_network_autograd(inputs, viewdirs, fn):
-    _no_backward("run_network")
+    """run_network (run_nerf.py:37-51) with the encodings fused, parameter gradients only."""
+    _no_input_grad(inputs, "inputs")
+    _no_input_grad(viewdirs, "viewdirs")
+    params = _params(fn)
+    S = inputs.shape[-2] if inputs.dim() >= 2 else 1
+    pts = inputs.reshape(-1, 3).contiguous().float()
+    R = pts.shape[0] // S
+    vd = viewdirs.reshape(-1, 3).contiguous().float()
+    if vd.shape[0] != R:
+        raise ValueError("viewdirs has %d rows for %d rays" % (vd.shape[0], R))
+    out = _NetworkFn.apply(fn, hip.IN_POINTS, pts, vd, R, S, 0, *params)
+    return out.reshape(list(inputs.shape[:-1]) + [4])
 
 
-def raw2outputs_autograd(*a, **k):
-    _no_backward("raw2outputs")
+def raw2outputs_autograd(raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest):
+    from .render import _density_noise
+    _no_input_grad(z_vals, "z_vals")
+    _no_input_grad(rays_d, "rays_d")
+    d = rays_d.reshape(-1, 3)
+    if d.dtype != torch.float32 or d.stride(-1) != 1:
+        d = d.float().contiguous()
+    noise = _density_noise(raw[..., 3].shape, raw_noise_std, pytest, raw.device)
+    return _CompositeFn.apply(raw.contiguous(), z_vals.contiguous(), d, d.stride(0), noise, bool(white_bkgd))
 
 
-def render_rays_autograd(*a, **k):
-    _no_backward("render_rays")
+def render_rays_autograd(rays, z_vals, network_fn, network_query_fn, N_samples, retraw, perturb, N_importance,
+                         network_fine, white_bkgd, raw_noise_std, pytest, with_depth):
+    """render_rays (run_nerf.py:314-424) when a network requires grad.  Same launches as the inference path
+    plus the tape; the importance samples are not differentiated (z_samples.detach(), run_nerf.py:399)."""
+    from .render import NetworkQuery, _density_noise
+    from .helpers import _pdf_variates
+    _no_input_grad(rays, "ray_batch")
+    N_rays, cols = rays.shape
+    dev = rays.device
+    has_vd = cols > 8
+    viewdirs = rays[:, -3:] if has_vd else None
+    rays_d = rays[:, 3:6]
+    fused = isinstance(network_query_fn, NetworkQuery)
+
+    def query(net, z):
+        needs = isinstance(net, torch.nn.Module) and any(p.requires_grad for p in net.parameters())
+        if fused and network_query_fn.fusable(net, has_vd):
+            if needs:
+                out = _NetworkFn.apply(net, hip.IN_RAYS, rays, z, N_rays, z.shape[1], cols, *_params(net))
+            else:
+                prec = net.precision_code()
+                out = hip.mlp_forward(net.packed_weights(prec), prec, net.use_viewdirs, net.out_channels, hip.IN_RAYS,
+                                      rays, z, N_rays, z.shape[1], cols)
+            return out.reshape(N_rays, z.shape[1], out.shape[-1])
+        pts = rays[:, None, 0:3] + rays_d[:, None, :] * z[:, :, None]
+        return network_query_fn(pts, viewdirs, net)
+
+    def composite(raw, z):
+        noise = _density_noise(raw[..., 3].shape, raw_noise_std, pytest, dev)
+        if raw.requires_grad:
+            return _CompositeFn.apply(raw.contiguous(), z, rays_d, cols, noise, bool(white_bkgd))
+        return hip.raw2outputs(raw, z, rays_d, cols, noise, white_bkgd)
+
+    raw = query(network_fn, z_vals)
+    rgb_map, disp_map, acc_map, weights, depth_map = composite(raw, z_vals)
+    ret0 = None
+    z_std = None
+    if N_importance > 0:
+        ret0 = (rgb_map, disp_map, acc_map)
+        u = _pdf_variates((N_rays,), N_importance, perturb == 0., pytest, dev)
+        _, _, z_vals, z_std = hip.sample_pdf(z_vals, weights.detach()[:, 1:-1], u, bins_are_z=True, z_vals=z_vals,
+                                             want_samples=False, want_sorted=True, want_std=True)
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = query(run_fn, z_vals)
+        rgb_map, disp_map, acc_map, weights, depth_map = composite(raw, z_vals)
+
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+    if with_depth:
+        ret['depth_map'] = depth_map
+    if retraw:
+        ret['raw'] = raw
+    if ret0 is not None:
+        ret['rgb0'], ret['disp0'], ret['acc0'] = ret0
+        ret['z_std'] = z_std
+    return ret
+
+
+# ---------------------------------------------------------------------------- the step itself (run_nerf.py:770-796)
+def train_step(rays, target, render_kwargs, optimizer, global_step, lrate, lrate_decay, chunk=1024 * 32):
+    """One optimisation step as the reference's loop body does it: render the ray batch [N, 8|11], loss =
+    img2mse(rgb, target) (+ img2mse(rgb0, target)), backward, optimizer.step(), then the exponential learning-rate
+    decay 0.1 ** (global_step / (lrate_decay * 1000)).  Returns (loss, psnr) as tensors."""
+    from .helpers import img2mse, mse2psnr
+    from .render import batchify_rays
+    kw = {k: v for k, v in render_kwargs.items() if k not in ("near", "far", "use_viewdirs", "ndc")}
+    ret = batchify_rays(rays, chunk, **kw)
+    optimizer.zero_grad()
+    img_loss = img2mse(ret['rgb_map'], target)
+    loss = img_loss
+    psnr = mse2psnr(img_loss.detach())
+    if 'rgb0' in ret:
+        loss = loss + img2mse(ret['rgb0'], target)
+    loss.backward()
+    optimizer.step()
+    new_lrate = lrate * (0.1 ** (global_step / (lrate_decay * 1000)))
+    for group in optimizer.param_groups:
+        group['lr'] = new_lrate
+    return loss.detach(), psnr

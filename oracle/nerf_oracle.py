@@ -342,6 +342,111 @@ def render_rays(rays, sd_coarse, N_samples, N_importance=0, sd_fine=None, use_vi
     return ret
 
 
+# --------------------------------------------------------------------------
+# backward (the reference differentiates run_nerf.py:268-311 and
+# run_nerf_helpers.py:96-119 with autograd; run_nerf.py:776-785 is the loss)
+# --------------------------------------------------------------------------
+def raw2outputs_backward(raw, z_vals, rays_d, noise=None, white_bkgd=False, g_rgb=None, g_disp=None, g_acc=None,
+                         g_depth=None):
+    """dL/draw [R,S,C] for upstream gradients of the maps, in float64 closed form (what autograd yields for
+    raw2outputs): c = sigmoid(raw_rgb), e = exp(-relu(sigma) dist), T = exclusive cumprod(e + 1e-10), w = (1-e) T."""
+    R, S, C = raw.shape
+    f = np.float64
+    z = z_vals.astype(f)
+    dists = np.concatenate([z[:, 1:] - z[:, :-1], np.full((R, 1), 1e10)], -1) * np.linalg.norm(rays_d.astype(f), axis=-1)[:, None]
+    with np.errstate(over="ignore"):
+        c = 1.0 / (1.0 + np.exp(-raw[..., :3].astype(f)))
+    pre = raw[..., 3].astype(f) + (0.0 if noise is None else noise.astype(f))
+    sig = np.maximum(pre, 0)
+    e = np.exp(-sig * dists)
+    alpha = 1.0 - e
+    one_m = (1.0 - alpha) + 1e-10
+    T = np.cumprod(np.concatenate([np.ones((R, 1)), one_m], -1), -1)[:, :-1]
+    w = alpha * T
+    acc, depth = w.sum(-1), (w * z).sum(-1)
+    zero = np.zeros(R)
+    g_rgb = np.zeros((R, 3)) if g_rgb is None else g_rgb.astype(f)
+    ga = zero if g_acc is None else g_acc.astype(f)
+    gd = zero if g_depth is None else g_depth.astype(f)
+    if g_disp is not None:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            q = depth / acc
+            disp = 1.0 / q
+            live = ~(q <= 1e-10) & (g_disp != 0)
+            gd = gd + np.where(live, g_disp * (-disp * disp / acc), 0.0)
+            ga = ga + np.where(live, g_disp * (disp * disp * depth / (acc * acc)), 0.0)
+    qw = (c * g_rgb[:, None, :]).sum(-1) - (g_rgb.sum(-1)[:, None] if white_bkgd else 0.0) + ga[:, None] + gd[:, None] * z
+    term = qw * w
+    suffix = np.cumsum(term[:, ::-1], -1)[:, ::-1] - term          # sum over later samples
+    dalpha = qw * T - suffix / one_m
+    dsig = np.where(pre > 0, dalpha * dists * e, 0.0)
+    out = np.zeros((R, S, C))
+    out[..., :3] = w[..., None] * g_rgb[:, None, :] * c * (1.0 - c)
+    out[..., 3] = dsig
+    return out
+
+
+def mlp_backward(sd, feat, d_raw):
+    """Gradients of the 24 parameter tensors of the view-dependent network for dL/draw = d_raw [N,4], float64.
+    Returns {state_dict name: gradient}."""
+    f = np.float64
+    W = {k: v.astype(f) for k, v in sd.items()}
+    x = feat.astype(f)
+    pts, views = x[:, :63], x[:, 63:90]
+    ins, pre = [], []
+    h = pts
+    for i in range(8):
+        ins.append(h)
+        a = h @ W["pts_linears.%d.weight" % i].T + W["pts_linears.%d.bias" % i]
+        pre.append(a)
+        h = np.maximum(a, 0)
+        if i == 4:
+            h = np.concatenate([pts, h], -1)
+    h8 = h
+    feature = h8 @ W["feature_linear.weight"].T + W["feature_linear.bias"]
+    hv_in = np.concatenate([feature, views], -1)
+    hv_pre = hv_in @ W["views_linears.0.weight"].T + W["views_linears.0.bias"]
+    hv = np.maximum(hv_pre, 0)
+    g = {}
+    d = d_raw.astype(f)
+    d_rgb, d_sig = d[:, :3], d[:, 3:4]
+    g["rgb_linear.weight"], g["rgb_linear.bias"] = d_rgb.T @ hv, d_rgb.sum(0)
+    d_hv = (d_rgb @ W["rgb_linear.weight"]) * (hv_pre > 0)
+    g["views_linears.0.weight"], g["views_linears.0.bias"] = d_hv.T @ hv_in, d_hv.sum(0)
+    d_feat = (d_hv @ W["views_linears.0.weight"])[:, :256]
+    g["feature_linear.weight"], g["feature_linear.bias"] = d_feat.T @ h8, d_feat.sum(0)
+    g["alpha_linear.weight"], g["alpha_linear.bias"] = d_sig.T @ h8, d_sig.sum(0)
+    dh = d_feat @ W["feature_linear.weight"] + d_sig @ W["alpha_linear.weight"]
+    for i in range(7, -1, -1):
+        dz = dh * (pre[i] > 0)
+        g["pts_linears.%d.weight" % i], g["pts_linears.%d.bias" % i] = dz.T @ ins[i], dz.sum(0)
+        dh = dz @ W["pts_linears.%d.weight" % i]
+        if i == 5:
+            dh = dh[:, 63:]
+    return g
+
+
+def train_step_grads(rays, target, sd_coarse, sd_fine, N_samples=64, N_importance=128, white_bkgd=True, t_rand=None,
+                     u=None, noise0=None, noise1=None):
+    """Loss img2mse(rgb_map, target) + img2mse(rgb0, target) (run_nerf.py:776-785) and its gradients with respect
+    to both networks.  Returns (loss, grads_coarse, grads_fine)."""
+    r = render_rays(rays, sd_coarse, N_samples, N_importance, sd_fine=sd_fine, white_bkgd=white_bkgd, t_rand=t_rand,
+                    u=u, noise0=noise0, noise1=noise1, retraw=True)
+    R = rays.shape[0]
+    d, vd = rays[:, 3:6], rays[:, 8:11]
+    loss = img2mse(r["rgb_map"].astype(np.float64), target) + img2mse(r["rgb0"].astype(np.float64), target)
+    out = []
+    for raw, z, rgb, noise, sd in ((r["raw0"], r["z_vals0"], r["rgb0"], noise0, sd_coarse),
+                                   (r["raw"], r["z_vals"], r["rgb_map"], noise1, sd_fine)):
+        g_rgb = 2.0 * (rgb.astype(np.float64) - target) / (3.0 * R)
+        d_raw = raw2outputs_backward(raw, z, d, noise, white_bkgd, g_rgb=g_rgb)
+        S = z.shape[1]
+        pts = (rays[:, None, 0:3] + d[:, None, :] * z[:, :, None]).reshape(-1, 3)
+        feat = np.concatenate([embed(pts, 10), embed(np.repeat(vd, S, 0), 4)], -1)
+        out.append(mlp_backward(sd, feat, d_raw.reshape(-1, 4)))
+    return loss, out[0], out[1]
+
+
 def render_image(H, W, K, c2w, sd_coarse, near, far, use_viewdirs=True, **kw):
     """render(H, W, K, c2w=...) of run_nerf.py:69-134: full image, maps shaped [H,W,...]."""
     o, d = get_rays(H, W, K, c2w)

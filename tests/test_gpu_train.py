@@ -1,0 +1,222 @@
+"""GPU parity of the training kernels: compositing backward, network backward (input-gradient chain and
+weight-gradient reductions) and one whole optimisation step against the reference's autograd results
+(tests/golden/g8_train_step.npz) and the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from nerf_loc_amd import synth
+from oracle import nerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nerf_loc_amd import hip
+    hip.lib()
+    return torch.device("cuda:0")
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def N(x):
+    return x.detach().cpu().numpy()
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def load_net(sd, dev, grad=True):
+    from nerf_loc_amd.helpers import NeRF
+    net = NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(dev).requires_grad_(grad)
+
+
+def _query(dev):
+    from nerf_loc_amd import helpers, render
+    return render.NetworkQuery(helpers.get_embedder(10, 0)[0], helpers.get_embedder(4, 0)[0], 1024 * 64)
+
+
+@pytest.mark.parametrize("S,white,with_noise", [(64, True, False), (192, True, True), (5, False, False), (130, False, True)])
+def test_raw2outputs_backward(dev, S, white, with_noise):
+    from nerf_loc_amd import hip
+    rs = np.random.RandomState(S)
+    R = 257
+    raw = (rs.randn(R, S, 4) * np.array([1, 1, 1, 8.0])).astype(F32)
+    raw[::7, :, 3] = -np.abs(raw[::7, :, 3])                      # empty rays: acc = 0
+    z = np.sort(rs.uniform(2, 6, size=(R, S)), -1).astype(F32)
+    d = rs.randn(R, 3).astype(F32)
+    noise = rs.randn(R, S).astype(F32) if with_noise else None
+    g_rgb = rs.randn(R, 3).astype(F32)
+    g_acc, g_depth, g_disp = rs.randn(R).astype(F32), rs.randn(R).astype(F32), rs.randn(R).astype(F32)
+    g_disp[::7] = 0.0                                              # disp is NaN there; autograd would give NaN too
+    dt = T(d, dev)
+    for extra in (False, True):
+        kw = dict(g_rgb=g_rgb)
+        if extra:
+            kw.update(g_acc=g_acc, g_depth=g_depth, g_disp=g_disp)
+        ref = orc.raw2outputs_backward(raw, z, d, noise, white, **kw)
+        got = hip.raw2outputs_backward(T(raw, dev), T(z, dev), dt, 3, None if noise is None else T(noise, dev), white,
+                                       **{k: T(v, dev) for k, v in kw.items()})
+        e = relerr(N(got), ref)
+        print("S=%d white=%s noise=%s extra=%s: rel err %.2e" % (S, white, with_noise, extra, e))
+        assert e < 2e-4
+
+
+def test_raw2outputs_autograd_matches_torch(dev):
+    """The autograd node against torch autograd over the same formula in float64 on CPU."""
+    from nerf_loc_amd import render
+    rs = np.random.RandomState(3)
+    R, S = 64, 64
+    raw = (rs.randn(R, S, 4) * np.array([1, 1, 1, 5.0])).astype(F32)
+    z = np.sort(rs.uniform(2, 6, size=(R, S)), -1).astype(F32)
+    d = rs.randn(R, 3).astype(F32)
+    tgt = rs.uniform(size=(R, 3)).astype(F32)
+    rt = T(raw, dev).requires_grad_(True)
+    rgb, disp, acc, w, depth = render.raw2outputs(rt, T(z, dev), T(d, dev), 0, True)
+    assert not w.requires_grad
+    loss = ((rgb - T(tgt, dev)) ** 2).mean() + 0.1 * acc.mean() + 0.01 * depth.mean()
+    loss.backward()
+    r64 = torch.tensor(raw, dtype=torch.float64, requires_grad=True)
+    z64, d64 = torch.tensor(z, dtype=torch.float64), torch.tensor(d, dtype=torch.float64)
+    dists = torch.cat([z64[:, 1:] - z64[:, :-1], torch.full((R, 1), 1e10, dtype=torch.float64)], -1) * d64.norm(dim=-1, keepdim=True)
+    alpha = 1 - torch.exp(-torch.relu(r64[..., 3]) * dists)
+    Tr = torch.cumprod(torch.cat([torch.ones(R, 1, dtype=torch.float64), 1 - alpha + 1e-10], -1), -1)[:, :-1]
+    w64 = alpha * Tr
+    rgb64 = (w64[..., None] * torch.sigmoid(r64[..., :3])).sum(-2) + (1 - w64.sum(-1, keepdim=True))
+    l64 = ((rgb64 - torch.tensor(tgt, dtype=torch.float64)) ** 2).mean() + 0.1 * w64.sum(-1).mean() + 0.01 * (w64 * z64).sum(-1).mean()
+    l64.backward()
+    assert abs(float(loss.detach()) - float(l64.detach())) < 1e-6
+    assert relerr(N(rt.grad), r64.grad.numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("M", [77, 1000, 40000])
+def test_network_backward_vs_oracle(dev, M):
+    from nerf_loc_amd import hip
+    sd = synth.make_state_dict(70 + M % 7, "B")
+    net = load_net(sd, dev)
+    rs = np.random.RandomState(M)
+    x = rs.uniform(-3, 3, size=(M, 3)).astype(F32)
+    d = rs.normal(size=(M, 3))
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(F32)
+    feat = np.concatenate([orc.embed(x, 10), orc.embed(d, 4)], -1)
+    d_raw = rs.randn(M, 4).astype(F32)
+    out = net(T(feat, dev))
+    with torch.no_grad():
+        net.precision = "fp32"
+        ref_out = net(T(feat, dev))
+    assert torch.equal(out.detach(), ref_out)                      # the tape does not change the forward result
+    out.backward(T(d_raw, dev))
+    ref = orc.mlp_backward(sd, feat, d_raw)
+    # A unit whose pre-activation is within float32 rounding of zero has its ReLU mask decided differently by the
+    # float64 oracle: about 3 units per million, each moving one sample's contribution.  Small batches are held to
+    # 2e-5 elementwise; the large one to 2e-2 elementwise and 2e-3 in Frobenius norm (perturbing the weights by
+    # 1e-7 relative moves the float64 result itself by 5.5e-3 / 7e-4 on this input).
+    worst = worst_fro = 0.0
+    for k, p in net.named_parameters():
+        e = relerr(N(p.grad), ref[k])
+        fro = float(np.linalg.norm(N(p.grad).astype(np.float64) - ref[k]) / np.linalg.norm(ref[k]))
+        worst, worst_fro = max(worst, e), max(worst_fro, fro)
+        assert e < (2e-5 if M <= 1000 else 2e-2) and fro < (2e-5 if M <= 1000 else 2e-3), (k, e, fro)
+    print("M=%d: worst gradient error over 24 tensors: elementwise/max %.2e, Frobenius %.2e" % (M, worst, worst_fro))
+
+
+def _grads_close(g, tag, pre, net, el):
+    names = [str(n) for n in g[pre + "_names"]]
+    norms = g["%s_%s_gradnorm" % (tag, pre)]
+    named = dict(net.named_parameters())
+    worst = 0.0
+    for n, ref in zip(names, norms):
+        got = float(named[n].grad.norm())
+        assert abs(got - ref) <= (2e-4 if pre == "c" else 2e-3) * max(ref, 1e-6), (tag, pre, n, got, ref)
+        key = "%s_%s_grad_%s" % (tag, pre, n)
+        if key in g:
+            e = relerr(N(named[n].grad), g[key])
+            worst = max(worst, e)
+            assert e <= el, (tag, pre, n, e)
+    for key, sl in (("pts0w", (slice(None), slice(None))), ("pts5w_sub", (slice(None, None, 8), slice(None, None, 11))),
+                    ("viewsw_sub", (slice(None, None, 4), slice(None, None, 9)))):
+        name = {"pts0w": "pts_linears.0.weight", "pts5w_sub": "pts_linears.5.weight", "viewsw_sub": "views_linears.0.weight"}[key]
+        e = relerr(N(named[name].grad)[sl], g["%s_%s_grad_%s" % (tag, pre, key)])
+        worst = max(worst, e)
+        assert e <= el, (tag, pre, key, e)
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["det", "stoch"])
+def test_train_step_matches_reference_autograd(dev, golden, tag):
+    """render_rays with networks that require grad, the loss of run_nerf.py:776-785 and backward(): loss and the
+    gradients of all 48 tensors against the reference's autograd."""
+    from nerf_loc_amd import render, helpers
+    g = golden("g8_train_step")
+    rays, target = T(g["rays"], dev), T(g["target"], dev)
+    nc, nf = load_net(synth.make_state_dict(80, "B"), dev), load_net(synth.make_state_dict(81, "B"), dev)
+    kw = dict(perturb=0.0, raw_noise_std=0.0) if tag == "det" else dict(perturb=1.0, raw_noise_std=1.0, pytest=True)
+    r = render.render_rays(rays, nc, _query(dev), 64, N_importance=128, network_fine=nf, white_bkgd=True, retraw=True, **kw)
+    assert r["rgb_map"].requires_grad and r["rgb0"].requires_grad and not r["z_std"].requires_grad
+    l1, l0 = helpers.img2mse(r["rgb_map"], target), helpers.img2mse(r["rgb0"], target)
+    loss = l1 + l0
+    loss.backward()
+    print("%s: loss %.8f (reference %.8f), psnr %.4f (reference %.4f)"
+          % (tag, float(loss.detach()), float(g[tag + "_loss"]), float(helpers.mse2psnr(l1.detach())), float(g[tag + "_psnr"][0])))
+    assert abs(float(loss.detach()) - float(g[tag + "_loss"])) < 2e-6
+    assert abs(float(helpers.mse2psnr(l1.detach())) - float(g[tag + "_psnr"][0])) < 1e-3
+    wc = _grads_close(g, tag, "c", nc, 1e-4 if tag == "det" else 3e-4)
+    wf = _grads_close(g, tag, "f", nf, 5e-3)       # fine sample positions are ill-conditioned in empty bins
+    print("  worst elementwise relative error: coarse %.2e, fine %.2e" % (wc, wf))
+
+
+def test_generic_composition_gives_the_same_gradients(dev, golden):
+    """Embedding -> NeRF.forward -> raw2outputs as separate differentiable calls (what a foreign training loop
+    does) against the fused render_rays."""
+    from nerf_loc_amd import render, helpers
+    g = golden("g8_train_step")
+    rays, target = T(g["rays"], dev), T(g["target"], dev)
+    sd = synth.make_state_dict(80, "B")
+    grads = []
+    for mode in ("fused", "generic"):
+        net = load_net(sd, dev)
+        if mode == "fused":
+            r = render.render_rays(rays, net, _query(dev), 64, white_bkgd=True)
+            rgb = r["rgb_map"]
+        else:
+            from nerf_loc_amd import hip
+            z = hip.z_vals(rays, 64)
+            pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
+            e10, e4 = helpers.get_embedder(10, 0)[0], helpers.get_embedder(4, 0)[0]
+            feat = torch.cat([e10(pts.reshape(-1, 3)), e4(rays[:, None, 8:11].expand(pts.shape).reshape(-1, 3))], -1)
+            raw = net(feat).reshape(rays.shape[0], 64, 4)
+            rgb = render.raw2outputs(raw, z, rays[:, 3:6], 0, True)[0]
+        helpers.img2mse(rgb, target).backward()
+        grads.append({k: N(p.grad) for k, p in net.named_parameters()})
+    for k in grads[0]:
+        assert relerr(grads[1][k], grads[0][k]) < 1e-4, k
+
+
+def test_optimisation_reduces_the_loss(dev):
+    """A few Adam steps through train.train_step on a fixed batch."""
+    from nerf_loc_amd import train
+    rays = T(synth.random_rays(512, seed=4), dev)
+    rs = np.random.RandomState(4)
+    target = T(rs.uniform(0, 1, size=(512, 3)).astype(F32), dev)
+    nc, nf = load_net(synth.make_state_dict(7, "A"), dev), load_net(synth.make_state_dict(8, "A"), dev)
+    opt = torch.optim.Adam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    kw = dict(network_query_fn=_query(dev), perturb=1.0, N_importance=128, network_fine=nf, N_samples=64, network_fn=nc,
+              white_bkgd=True, raw_noise_std=0.0)
+    losses = []
+    for step in range(12):
+        loss, psnr = train.train_step(rays, target, kw, opt, step + 1, 5e-4, 250)
+        losses.append(float(loss))
+    print("losses:", " ".join("%.4f" % l for l in losses))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert abs(opt.param_groups[0]["lr"] - 5e-4 * 0.1 ** (12 / 250000.0)) < 1e-12

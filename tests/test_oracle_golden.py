@@ -234,3 +234,47 @@ def test_render_image(golden):
     assert maxabs(r["depth_map"], g["loc_depth"]) < 5e-5
     assert maxabs(r["acc_map"], g["loc_acc"]) < 1e-5
     assert maxabs(r["raw"], g["loc_raw"]) < 3e-5 * max(1.0, np.abs(g["loc_raw"]).max())
+
+
+def _check_grads(g, tag, pre, grads):
+    # coarse network: identical sample positions in both runs -> 1e-4 (float32 autograd sums vs float64 here); fine network: its sample positions are
+    # importance samples, a few of which sit in empty bins and move with 1-ulp changes of the coarse weights
+    el = 1e-4 if pre == "c" else 5e-3
+    names = [str(n) for n in g[pre + "_names"]]
+    norms = g["%s_%s_gradnorm" % (tag, pre)]
+    for n, ref in zip(names, norms):
+        got = np.linalg.norm(grads[n])
+        assert abs(got - ref) <= 2e-4 * max(ref, 1e-6), (tag, pre, n, got, ref)
+    for n in names:
+        key = "%s_%s_grad_%s" % (tag, pre, n)
+        if key in g:
+            ref = g[key]
+            assert np.abs(grads[n] - ref).max() <= el * max(np.abs(ref).max(), 1e-7), (tag, pre, n)
+    sc = lambda a: max(np.abs(a).max(), 1e-7)
+    assert np.abs(grads["pts_linears.0.weight"] - g["%s_%s_grad_pts0w" % (tag, pre)]).max() <= el * sc(g["%s_%s_grad_pts0w" % (tag, pre)])
+    assert np.abs(grads["pts_linears.5.weight"][::8, ::11] - g["%s_%s_grad_pts5w_sub" % (tag, pre)]).max() <= el * sc(g["%s_%s_grad_pts5w_sub" % (tag, pre)])
+    assert np.abs(grads["views_linears.0.weight"][::4, ::9] - g["%s_%s_grad_viewsw_sub" % (tag, pre)]).max() <= el * sc(g["%s_%s_grad_viewsw_sub" % (tag, pre)])
+
+
+def test_train_step_gradients(golden):
+    """Backward restatement against one training step of the reference (loss and autograd gradients of both
+    networks), deterministic and with the numpy-seeded stochastic hooks (perturb = 1, raw_noise_std = 1)."""
+    g = golden("g8_train_step")
+    rays, target = g["rays"], g["target"]
+    sc, sf = synth.make_state_dict(80, "B"), synth.make_state_dict(81, "B")
+    loss, gc, gf = orc.train_step_grads(rays, target, sc, sf)
+    assert abs(loss - float(g["det_loss"])) < 1e-6
+    _check_grads(g, "det", "c", gc)
+    _check_grads(g, "det", "f", gf)
+    # stochastic hooks: every draw is preceded by np.random.seed(0) in the reference (run_nerf.py:377-380,
+    # 294-297, run_nerf_helpers.py:211-218)
+    def draw(*shape):
+        np.random.seed(0)
+        return np.random.rand(*shape)
+    R = rays.shape[0]
+    loss, gc, gf = orc.train_step_grads(rays, target, sc, sf, t_rand=draw(R, 64).astype(np.float32),
+                                        u=draw(R, 128).astype(np.float32), noise0=draw(R, 64).astype(np.float32),
+                                        noise1=draw(R, 192).astype(np.float32))
+    assert abs(loss - float(g["stoch_loss"])) < 1e-6
+    _check_grads(g, "stoch", "c", gc)
+    _check_grads(g, "stoch", "f", gf)
