@@ -259,18 +259,28 @@ void wgrad_kernel(WgradArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][ct][e] = 0.0f;
     float bs0 = 0.0f, bs1 = 0.0f;
 
-    const bool g0ok = row0 + r < a.N, g1ok = row0 + 32 + r < a.N;
+    // N is a multiple of 32 and K = 32 CT (checked by the host), so only the sample index needs a bound.  Loads
+    // are unconditional from a clamped row and zeroed by a select: no branches in the loop.
     constexpr int DEPTH = 4;                       // k-steps of operands in flight
     float ga[DEPTH][2], xb[DEPTH][CT];
+    const float* Gp = a.G + row0 + r;
+    const float* Xp = a.X + r;
+    const long long last = m1 - 1;
     auto load = [&](int slot, long long m) {
         const long long mm = m + h;
         const bool ok = mm < m1;
-        const float* gp = a.G + (size_t)(ok ? mm : m0) * a.ldg + row0 + r;
-        const float* xp = a.X + (size_t)(ok ? mm : m0) * a.ldx + r;
-        ga[slot][0] = (ok && g0ok) ? gp[0] : 0.0f;
-        ga[slot][1] = (ok && g1ok) ? gp[32] : 0.0f;
+        const long long mc = ok ? mm : last;
+        const float* gp = Gp + (size_t)mc * a.ldg;
+        const float* xp = Xp + (size_t)mc * a.ldx;
+        const float g0 = gp[0];
+        const float g1 = two ? gp[32] : 0.0f;      // wave-uniform condition
+        float xv[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) xb[slot][ct] = (ok && 32 * ct + r < a.K) ? xp[32 * ct] : 0.0f;
+        for (int ct = 0; ct < CT; ++ct) xv[ct] = xp[32 * ct];
+        ga[slot][0] = ok ? g0 : 0.0f;
+        ga[slot][1] = ok ? g1 : 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) xb[slot][ct] = ok ? xv[ct] : 0.0f;
     };
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) load(d, m0 + 2 * d);
@@ -278,7 +288,7 @@ void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const long long m = mb + 2 * d;
-            load((d + DEPTH - 1) % DEPTH, m + 2 * (DEPTH - 1));      // rows beyond m1 load zeros
+            load((d + DEPTH - 1) % DEPTH, m + 2 * (DEPTH - 1));      // rows beyond m1 give zeros
             const float g0 = ga[d][0], g1 = ga[d][1];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
@@ -351,14 +361,22 @@ __global__ void wgrad_reduce_kernel(ReduceArgs a) {
     if (dc < 0) return;
     const float* p = a.part + (size_t)row * a.pcol + col;
     const size_t stride = (size_t)a.prow * a.pcol;
-    float s = 0.0f;
-    for (int i = 0; i < a.n_parts; ++i) s += p[i * stride];
-    a.dst[(size_t)row * a.ld + a.col_off + dc] = s;
+    // eight interleaved chains keep eight loads in flight; the order of additions is fixed
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 8 <= a.n_parts; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += p[(size_t)(i + j) * stride];
+    }
+    for (int j = 0; i < a.n_parts; ++i, ++j) s[j] += p[(size_t)i * stride];
+    a.dst[(size_t)row * a.ld + a.col_off + dc] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 static int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K, long long M,
                         float* ws, float* dW, int ld, int col_off, int map, float* db, hipStream_t st) {
     const int ct = (K + 31) / 32;
+    NERF_REQUIRE(N % 32 == 0 && N <= 256 && (K == 32 || K == 64 || K == 128 || K == 256),
+                 "weight gradient: unsupported shape %d x %d", N, K);
     long long parts = (M + 511) / 512;             // at least 512 samples per workgroup
     if (parts > WG_MAX_PARTS) parts = WG_MAX_PARTS;
     if (parts > cu_count()) parts = cu_count();

@@ -42,6 +42,22 @@ def main():
     got = ndist.render_rays_sharded(rays, fake_render, keys=["rgb_map", "depth_map"])
     res["subset_ok"] = bool(sorted(got) == ["depth_map", "rgb_map"] and torch.equal(got["rgb_map"], fake_render(rays)["rgb_map"]))
     res["objects"] = ndist.objects_of_rank(5, rank, world)
+    # data-parallel gradient exchange: the mean over ranks of per-rank mean-loss gradients equals the gradient of
+    # the global mean loss for equal shards
+    torch.manual_seed(0)
+    nets = [torch.nn.Linear(5, 3), torch.nn.Linear(3, 2)]
+    x = torch.randn(8, 5, generator=torch.Generator().manual_seed(11))
+    y = torch.randn(8, 2, generator=torch.Generator().manual_seed(12))
+    xs, ys = ndist.shard_batch(x, y)
+    ((nets[1](torch.relu(nets[0](xs))) - ys) ** 2).mean().backward()
+    n = ndist.average_gradients(nets)
+    got = torch.cat([p.grad.reshape(-1) for m in nets for p in m.parameters()])
+    for m in nets:
+        m.zero_grad()
+    ((nets[1](torch.relu(nets[0](x))) - y) ** 2).mean().backward()
+    want = torch.cat([p.grad.reshape(-1) for m in nets for p in m.parameters()])
+    res["dp_ok"] = bool(n == got.numel() and torch.allclose(got, want, atol=1e-6))
+    res["dp_shard"] = int(xs.shape[0])
     torch.distributed.barrier()
     with open(out_path + ".%d" % rank, "w") as f:
         json.dump(res, f)

@@ -73,6 +73,7 @@ def test_world_size_two_gloo(tmp_path):
     res = [json.load(open(out + ".%d" % r)) for r in range(2)]
     for r, x in enumerate(res):
         assert x["rank"] == r and x["world"] == 2 and x["subset_ok"]
+        assert x["dp_ok"] and x["dp_shard"] == 4
         for n, c in x["cases"].items():
             assert c["ok"], (r, n, c)
     # n = 1: rank 1 holds an empty shard and renders only a 1-ray probe for the key list

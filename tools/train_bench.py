@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Times the training iteration of BASELINE configuration 5 on one GPU: 4096 rays, 64 + 128 samples, stratified
+jitter, forward + backward through both networks + Adam (run_nerf.py:770-796).  Prints ms/iteration and rays/s."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    from nerf_loc_amd import helpers, render, synth, train
+    dev = torch.device("cuda:0")
+
+    def net(seed):
+        n = helpers.NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(seed, "B").items()})
+        return n.to(dev)
+
+    nc, nf = net(0), net(1)
+    q = render.NetworkQuery(helpers.get_embedder(10, 0)[0], helpers.get_embedder(4, 0)[0], 1024 * 64)
+    kw = dict(network_query_fn=q, perturb=1.0, N_importance=128, network_fine=nf, N_samples=64, network_fn=nc,
+              white_bkgd=True, raw_noise_std=0.0)
+    opt = torch.optim.Adam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    rays = torch.from_numpy(synth.random_rays(args.rays, seed=0)).to(dev)
+    target = torch.rand(args.rays, 3, device=dev)
+    for i in range(args.warmup):
+        train.train_step(rays, target, kw, opt, i + 1, 5e-4, 500, chunk=1 << 20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = train.train_step(rays, target, kw, opt, i + 1, 5e-4, 500, chunk=1 << 20)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    flop = args.rays * 256 * 1186816 * 3.0
+    print(json.dumps({"workload": "train step, %d rays, 64+128, fp32" % args.rays, "ms_per_iter": dt * 1e3,
+                      "rays_per_s": args.rays / dt, "tflops_3x_fwd": flop / dt / 1e12, "loss": float(loss)}))
+
+
+if __name__ == "__main__":
+    main()
