@@ -66,20 +66,31 @@ struct SaveTile {
     }
 };
 
-// gradient tile: zero where the forward activation was not positive (ReLU), then store
+// gradient tile: zero where the forward activation was not positive (ReLU), then store.  The activation
+// tile is fetched one tile ahead of its use so that its latency hides under the previous tile's MFMAs.
+struct ActTile {
+    float4 q[4];
+};
 template <bool MASK>
 struct MaskSaveTile {
     const float* act;   // forward activation row of a valid sample (+ 4 h)
     float* row;         // destination row (+ 4 h) or nullptr
-    __device__ __forceinline__ void operator()(int t, float (&v)[16]) const {
+    __device__ __forceinline__ ActTile fetch(int t) const {
+        ActTile a;
+        if (MASK) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a.q[g] = *reinterpret_cast<const float4*>(act + 32 * t + 8 * g);
+        }
+        return a;
+    }
+    __device__ __forceinline__ void apply(int t, float (&v)[16], const ActTile& a) const {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (MASK) {
-                const float4 a = *reinterpret_cast<const float4*>(act + 32 * t + 8 * g);
-                v[4 * g + 0] = a.x > 0.0f ? v[4 * g + 0] : 0.0f;
-                v[4 * g + 1] = a.y > 0.0f ? v[4 * g + 1] : 0.0f;
-                v[4 * g + 2] = a.z > 0.0f ? v[4 * g + 2] : 0.0f;
-                v[4 * g + 3] = a.w > 0.0f ? v[4 * g + 3] : 0.0f;
+                v[4 * g + 0] = a.q[g].x > 0.0f ? v[4 * g + 0] : 0.0f;
+                v[4 * g + 1] = a.q[g].y > 0.0f ? v[4 * g + 1] : 0.0f;
+                v[4 * g + 2] = a.q[g].z > 0.0f ? v[4 * g + 2] : 0.0f;
+                v[4 * g + 3] = a.q[g].w > 0.0f ? v[4 * g + 3] : 0.0f;
             }
             if (row) *reinterpret_cast<float4*>(row + 32 * t + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
         }
@@ -164,8 +175,11 @@ struct DgradArgs {
 template <int NT, int NF, bool EXTRA, class Hook>
 __device__ __forceinline__ void layer_bwd_f32(Pipe& p, int& pos, const float* hin, const float (&ex)[4],
                                               float (&hout)[8][16], Hook hook) {
+    ActTile nxt = hook.fetch(0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        const ActTile cur = nxt;
+        if (t + 1 < NT) nxt = hook.fetch(t + 1);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
@@ -174,7 +188,7 @@ __device__ __forceinline__ void layer_bwd_f32(Pipe& p, int& pos, const float* hi
         if (EXTRA) { mma_run_f32<1>(p, pos, acc, &ex[0]); pos += 1; }
 #pragma unroll
         for (int e = 0; e < 16; ++e) hout[t][e] = acc[e];
-        hook(t, hout[t]);
+        hook.apply(t, hout[t], cur);
     }
 }
 
