@@ -88,6 +88,30 @@ def pmc_traffic(precision):
         return None
 
 
+def build_objects(device, precision, n_objects):
+    """BASELINE configuration 4: per-object networks rendering the detector's inputs.  Each object: 8 poses x 2
+    focal lengths (fine K and K/1.2) at 240 x 180, 64 samples, coarse network only, raw volume kept
+    (model_3detr.py:619-724 through nerf_utils.render_path)."""
+    import types
+    from nerf_loc_amd import nerf_utils, synth
+    args = types.SimpleNamespace(nerf_render_rgb=True, nerf_render_depth=True)
+    objs = []
+    for o in range(n_objects):
+        _, kw, _ = nerf_utils.create_nerf_model(args, ckpt_path=None, device=device, near=0.1, far=9.0)
+        net = kw["network_fn"]
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(100 + o, "B").items()})
+        net.requires_grad_(False)
+        net.precision = precision
+        objs.append(kw)
+    H, W, K, _, _, _ = synth.objectron_camera()
+    Kc = np.array(K, dtype=np.float64).copy()
+    Kc[0, 0] /= 1.2
+    Kc[1, 1] /= 1.2
+    poses = [torch.from_numpy(synth.pose_spherical(45.0 * i, -30.0, 4.0)[:3, :4].astype(np.float32)).to(device)
+             for i in range(8)]
+    return objs, H, W, K, Kc, poses
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,26 +121,97 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--chunk", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="view", choices=["view", "rays4m", "objects", "train"],
+                    help="view: BASELINE configs[1] (default, the headline line); rays4m: configs[2], a 4 194 304-ray "
+                         "batch split over the ranks; objects: configs[3], per-object networks dealt to the ranks; "
+                         "train: configs[4], 4096-ray training iteration, data parallel")
     args = ap.parse_args()
 
-    from nerf_loc_amd import dist as ndist, hip, render
+    from nerf_loc_amd import dist as ndist, hip, render, synth
     import torch.distributed as tdist
     rank, world, device = ndist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     hip.lib()
-    H, W, K, c2w, kwargs = build_scene(device, args.precision, args.res)
-    n_rays = H * W
     keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
-
-    def step():
-        rays_flat, _ = render._build_rays(H, W, K, None, c2w, False, kwargs["near"], kwargs["far"], True, None)
+    scaling = "weak"
+    flop_per_ray = 256 * FLOP_PER_SAMPLE
+    if args.workload in ("view", "rays4m"):
+        H, W, K, c2w, kwargs = build_scene(device, args.precision, args.res)
         rk = {k: v for k, v in kwargs.items() if k not in ("near", "far", "use_viewdirs", "ndc")}
-        ret = render.batchify_rays(rays_flat, args.chunk, **rk)
-        rec = ndist.pack_record(ret, keys)
-        if world > 1:
-            rec = ndist.all_gather_rows(rec, n_rays * world, n_rays)
-        return rec
+    if args.workload == "view":
+        n_rays = H * W                      # per rank
+        total_rays = n_rays * world
+        desc = ("BASELINE configs[1]: %dx%d view (%d rays/GPU), 64 coarse + 128 importance samples, D8/W256 L10/4 "
+                "viewdirs, separate fine net, seeded random weights, %s-MFMA mode" % (H, W, n_rays, args.precision))
+
+        def step():
+            rays_flat, _ = render._build_rays(H, W, K, None, c2w, False, kwargs["near"], kwargs["far"], True, None)
+            rec = ndist.pack_record(render.batchify_rays(rays_flat, args.chunk, **rk), keys)
+            return ndist.all_gather_rows(rec, n_rays * world, n_rays) if world > 1 else rec
+    elif args.workload == "rays4m":
+        scaling = "strong"
+        total_rays = 4194304
+        all_rays = torch.from_numpy(synth.random_rays(total_rays, seed=0)).to(device)
+        lo, hi, per = ndist.shard_bounds(total_rays, rank, world)
+        n_rays = hi - lo
+        desc = ("BASELINE configs[2]: 4 194 304 synthetic rays split over %d GPU(s), 64 + 128 samples, %s-MFMA mode, "
+                "one all-gather of the per-ray record" % (world, args.precision))
+
+        def step():
+            rec = ndist.pack_record(render.batchify_rays(all_rays[lo:hi], args.chunk, **rk), keys)
+            return ndist.all_gather_rows(rec, total_rays, per) if world > 1 else rec
+    elif args.workload == "objects":
+        from nerf_loc_amd import nerf_utils
+        n_obj = 8                           # per rank (weak scaling: 64 objects on 8 GPUs)
+        objs, H, W, K, Kc, poses = build_objects(device, args.precision, n_obj)
+        n_rays = n_obj * 2 * 8 * H * W
+        total_rays = n_rays * world
+        flop_per_ray = 64 * FLOP_PER_SAMPLE
+        desc = ("BASELINE configs[3]: %d objects/GPU x 2 focal lengths x 8 poses x %dx%d, 64 samples, coarse net, "
+                "rgb + depth + raw volume kept on device, %s-MFMA mode" % (n_obj, H, W, args.precision))
+
+        def step():
+            out = None
+            for kw in objs:
+                for Kx in (K, Kc):
+                    rgbs, disps, raws, depths = nerf_utils.render_path_device(poses, [H, W, float(Kx[0][0])], Kx, kw)
+                    out = rgbs.reshape(-1, 3)
+            return out
+    else:
+        from nerf_loc_amd import helpers, train
+        total = 4096
+        n_rays = total // world
+        total_rays = total
+        scaling = "strong"
+        flop_per_ray = 3 * 256 * FLOP_PER_SAMPLE
+        H, W, K, c2w, kwargs = build_scene(device, "fp32", 64)
+        for k in ("network_fn", "network_fine"):
+            kwargs[k].requires_grad_(True)
+        rk = {k: v for k, v in kwargs.items() if k not in ("near", "far", "use_viewdirs", "ndc")}
+        rk["perturb"] = 1.0
+        opt = torch.optim.Adam(list(kwargs["network_fn"].parameters()) + list(kwargs["network_fine"].parameters()),
+                               lr=5e-4, betas=(0.9, 0.999))
+        rays_all = torch.from_numpy(synth.random_rays(total, seed=0)).to(device)
+        tgt_all = torch.rand(total, 3, generator=torch.Generator().manual_seed(0)).to(device)
+        lo, hi, _ = ndist.shard_bounds(total, rank, world)
+        rays_l, tgt_l = rays_all[lo:hi], tgt_all[lo:hi]
+        args.precision = "fp32"
+        desc = ("BASELINE configs[4]: training iteration, 4096 rays over %d GPU(s), 64 + 128 samples, stratified "
+                "jitter, forward + backward of both networks + one gradient all-reduce + Adam, float32" % world)
+        it = [0]
+
+        def step():
+            ret = render.batchify_rays(rays_l, 1 << 20, **rk)
+            opt.zero_grad()
+            loss = helpers.img2mse(ret["rgb_map"], tgt_l) + helpers.img2mse(ret["rgb0"], tgt_l)
+            loss.backward()
+            ndist.average_gradients([kwargs["network_fn"], kwargs["network_fine"]])
+            opt.step()
+            it[0] += 1
+            for g in opt.param_groups:
+                g["lr"] = 5e-4 * (0.1 ** (it[0] / 500000.0))
+            return ret["rgb_map"].detach()
 
     def sync():
         if world > 1:
@@ -140,30 +235,41 @@ def main():
     assert torch.isfinite(out[:, :3]).all()
 
     if rank == 0:
-        ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
-        flops = [n * FLOP_PER_SAMPLE for _, _, n in events]
-        fine = [(m, f) for m, f in zip(ms, flops) if f == max(flops)]
-        ach = sum(f for _, f in fine) / (sum(m for m, _ in fine) * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
+        kname = "mlp_%s_kernel" % ("bf16" if args.precision == "bf16" else "f32")
+        if events:
+            ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+            flops = [n * FLOP_PER_SAMPLE for _, _, n in events]
+            big = [(m, f) for m, f in zip(ms, flops) if f == max(flops)]
+            ach = sum(f for _, f in big) / (sum(m for m, _ in big) * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "traffic": pmc_traffic(args.precision) if args.workload == "view" else None,
+                    "traffic_unit": "HBM-side bytes per largest launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate "
+                                    "PMC passes of the default command)",
+                    "algorithmic_bytes": big[0][1] // FLOP_PER_SAMPLE * 20 + n_rays * 44,
+                    "kernel": "%s (largest launches: %d samples each, avg %.3f ms)"
+                              % (kname, big[0][1] // FLOP_PER_SAMPLE, sum(m for m, _ in big) / len(big)),
+                    "all_launches_tflops": sum(flops) / (sum(ms) * 1e-3) / 1e12,
+                    "mlp_time_share": sum(ms) * 1e-3 / dt}
+        else:   # training: forward-with-tape, input-gradient and weight-gradient kernels, timed as a whole step
+            ach = n_rays * flop_per_ray * args.steps / dt / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                    "kernel": "whole iteration (mlp_f32_train_kernel + mlp_dgrad_f32_kernel + wgrad_kernel), "
+                              "3 x forward FLOPs per sample / step time"}
         line = {
-            "metric": "rendered rays/sec (64+128 samples)", "value": n_rays * world * args.steps / dt, "unit": "rays/s",
+            "metric": "rendered rays/sec (64+128 samples)" if args.workload in ("view", "rays4m") else
+                      ("rendered rays/sec (64 samples, coarse only)" if args.workload == "objects" else "training rays/sec (64+128 samples, fwd+bwd+Adam)"),
+            "value": total_rays * args.steps / dt, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %dx%d view (%d rays/GPU), 64 coarse + 128 importance samples, "
-                                   "D8/W256 L10/4 viewdirs, separate fine net, seeded random weights, %s-MFMA mode"
-                                   % (H, W, n_rays, args.precision),
-                       "rays_per_gpu": n_rays, "chunk": args.chunk, "parallelism": "ray-shard x%d + 1 all-gather" % world},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": pmc_traffic(args.precision), "traffic_unit": "HBM-side bytes per fine-pass launch "
-                         "(rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes of this command)",
-                         "algorithmic_bytes": fine[0][1] // FLOP_PER_SAMPLE * 20 + n_rays * 44, "kernel": "mlp_%s_kernel (fine pass launches: %d samples each, avg %.3f ms)"
-                                   % ("bf16" if args.precision == "bf16" else "f32", fine[0][1] // FLOP_PER_SAMPLE,
-                                      sum(m for m, _ in fine) / len(fine)),
-                         "all_launches_tflops": sum(flops) / (sum(ms) * 1e-3) / 1e12,
-                         "mlp_time_share": sum(ms) * 1e-3 / dt},
+            "config": {"workload": desc, "rays_per_gpu": n_rays, "chunk": args.chunk,
+                       "parallelism": "ray-shard x%d + 1 all-gather" % world if args.workload in ("view", "rays4m") else
+                                      ("objects round-robin x%d, no collective" % world if args.workload == "objects"
+                                       else "data parallel x%d, 1 gradient all-reduce" % world)},
+            "roofline": roof,
         }
-        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or args.workload != "view") else cpu_baseline()
         print(json.dumps(line))
     if world > 1:
         tdist.barrier()

@@ -144,3 +144,22 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, savedir=None, render
         if savedir is not None:
             _r._save_frame(savedir, i, rgbs[-1], extra['raw'] if render_kwargs.get('retraw') else None)
     return np.stack(rgbs, 0), np.stack(disps, 0), np.stack(raws, 0), np.stack(depths, 0)
+
+
+def render_path_device(render_poses, hwf, K, render_kwargs, render_factor=0):
+    """All poses of render_path in ONE ray batch, results left on the device: (rgbs [P,H,W,3], disps [P,H,W],
+    raws [P,H,W,S,C] or None, depths [P,H,W]).  The reference renders pose by pose and copies every result to
+    numpy (nerf_utils.py:107-151; model_3detr.py:619-724 then moves them back to the GPU); a detector that
+    consumes the maps as tensors calls this instead."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W = H // render_factor, W // render_factor
+    kw = dict(render_kwargs)
+    near, far = kw.pop('near', 0.), kw.pop('far', 1.)
+    use_viewdirs, ndc = kw.pop('use_viewdirs', False), kw.pop('ndc', False)
+    rays = torch.cat([_r._build_rays(H, W, K, None, c2w[:3, :4], ndc, near, far, use_viewdirs, None)[0]
+                      for c2w in render_poses], 0)
+    ret = batchify_rays(rays, rays.shape[0], **kw)
+    P = len(render_poses)
+    shp = lambda t: None if t is None else t.reshape([P, H, W] + list(t.shape[1:]))
+    return shp(ret['rgb_map']), shp(ret.get('disp_map')), shp(ret.get('raw')), shp(ret.get('depth_map'))

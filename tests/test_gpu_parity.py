@@ -430,6 +430,11 @@ def test_render_image_both_flavours(dev, golden):
                                                        kw_test)
     assert rgbs.shape == (2, H, W, 3) and raws.shape == (2, H, W, 64, 4) and depths.shape == (2, H, W)
     assert isinstance(rgbs, np.ndarray) and maxabs(rgbs[1], g["loc_rgb"]) < 1e-4
+    # all poses as one ray batch, results on the device: same numbers as pose by pose
+    d_rgbs, d_disps, d_raws, d_depths = nerf_utils.render_path_device(poses, [H, W, float(g["loc_K"][0, 0])], g["loc_K"],
+                                                                       kw_test)
+    assert d_rgbs.is_cuda and tuple(d_raws.shape) == (2, H, W, 64, 4)
+    assert np.array_equal(N(d_rgbs), rgbs) and np.array_equal(N(d_depths), depths) and np.array_equal(N(d_raws), raws)
 
 
 # ------------------------------------------------------------------ bf16 mode end to end
