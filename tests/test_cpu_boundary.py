@@ -187,3 +187,17 @@ def test_training_entry_points_say_what_is_missing():
     net = helpers.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True)
     with pytest.raises(NotImplementedError):
         net(torch.zeros(2, 90, requires_grad=True))
+
+
+def test_dropin_alias_modules_resolve_to_the_engine():
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import run_nerf, run_multi_nerf, run_nerf_helpers\n"
+            "from run_nerf_helpers import *\n"
+            "from utils.nerf_utils import create_nerf_model, load_nerf_model, render_path\n"
+            "assert NeRF.__module__.endswith('helpers') and run_multi_nerf.run_network is run_nerf.run_network\n"
+            "for n in ('render', 'render_rays', 'batchify', 'batchify_rays', 'raw2outputs', 'create_nerf', 'render_path',\n"
+            "          'sample_pdf', 'get_embedder', 'get_rays', 'get_rays_np', 'ndc_rays', 'img2mse', 'mse2psnr', 'to8b'):\n"
+            "    assert callable(getattr(run_nerf, n)), n\n"
+            "print('ALIAS OK')\n") % os.path.join(ROOT, "dropin")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert "ALIAS OK" in out.stdout, out.stdout + out.stderr
