@@ -175,7 +175,7 @@ void mlp_bf16_kernel(MlpArgs a) {
 
 #pragma unroll
     for (int k = 0; k < PF; ++k) st.fetch(k);
-    f32x16 bias = bias_tile(lds, 0, h);
+    f32x16 bias = bias_tile(st.p.lds, 0, h);
 
     // raw inputs are fetched one whole pass ahead: with a single wave per SIMD nothing else could
     // hide the HBM latency of a load issued where its value is needed

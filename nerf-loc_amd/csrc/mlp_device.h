@@ -17,7 +17,11 @@ constexpr int NSTAGE = 8;                   // LDS ring slots of STAGE_BYTES
 #endif
 constexpr int PREFETCH = NERF_PREFETCH;     // stages in flight beyond the one being made ready (<= NSTAGE-3)
 constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
-constexpr int LDS_BYTES = RING_BYTES + BIAS_TILES_VD * BIAS_TILE_BYTES;
+// LDS map: [bias tiles | padding to BIAS_PAD][ring].  The bias block comes first so that its ds_read
+// addresses fit the 16-bit instruction offset (no per-tile address arithmetic).
+constexpr int BIAS_PAD = 10240;
+constexpr int LDS_BYTES = BIAS_PAD + RING_BYTES;
+static_assert(BIAS_TILES_VD * BIAS_TILE_BYTES <= BIAS_PAD, "bias block");
 constexpr int MLP_THREADS = 256;
 static_assert(PREFETCH <= NSTAGE - 3, "a slot may be refilled only two stages after its last read");
 static_assert(PREFETCH * 4 <= 63, "vmcnt is a 6-bit counter");
@@ -53,7 +57,8 @@ struct MlpArgs {
 // weight stream: LDS ring fed by LDS-DMA
 // ------------------------------------------------------------------------------------------
 struct Pipe {
-    const unsigned char* src_lane;   // packed + wave * 4 KiB + lane * 16
+    const unsigned char* src;        // packed fragment stream (wave-uniform)
+    unsigned src_off;                // wave * 4 KiB + lane * 16
     unsigned char* lds;              // ring base
     unsigned lds_addr;               // the same as a 32-bit LDS byte address (for M0)
     unsigned wave_off;               // wave * 4 KiB: this wave's quarter of every stage
@@ -65,7 +70,10 @@ struct Pipe {
     unsigned next_read_slot;
 
     __device__ __forceinline__ void issue() {
-        const unsigned char* g = src_lane + (size_t)issue_src * STAGE_BYTES;
+        // wave-uniform 64-bit source of the stage (scalar registers) + one constant 32-bit lane offset
+        const unsigned long long g = reinterpret_cast<unsigned long long>(src) + (unsigned long long)issue_src * STAGE_BYTES;
+        const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)g), ghi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
+        const unsigned long long gs = ((unsigned long long)ghi << 32) | glo;
         // LDS-DMA: 4 x 1 KiB per wave.  The LDS address is M0 + lane*16 + the instruction offset.
         // Written as inline asm on purpose: once hipcc sees a global_load_lds it treats the
         // LDS counter as out of order and turns every counted "s_waitcnt lgkmcnt(N)" of the
@@ -76,13 +84,13 @@ struct Pipe {
             "s_mov_b32 %0, m0\n\t"
             "s_mov_b32 m0, %2\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
-            "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-            "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-            "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+            "global_load_lds_dwordx4 %1, %3\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
-            : "v"(g), "s"(m0v)
+            : "v"(src_off), "s"(m0v), "s"(gs)
             : "memory");
         issue_src = (issue_src + 1 == n_stages) ? 0 : issue_src + 1;
         issue_slot = (issue_slot + 1) & (NSTAGE - 1);
@@ -113,9 +121,10 @@ struct Pipe {
 
 __device__ __forceinline__ void pipe_start(Pipe& p, const MlpArgs& a, unsigned char* lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    p.src_lane = a.packed + wave * 4096 + lane * 16;
-    p.lds = lds;
-    p.lds_addr = (unsigned)(size_t)(lds_ptr_t)lds;
+    p.src = a.packed;
+    p.src_off = wave * 4096 + lane * 16;
+    p.lds = lds + BIAS_PAD;
+    p.lds_addr = (unsigned)(size_t)(lds_ptr_t)(lds + BIAS_PAD);
     p.wave_off = wave * 4096;
     p.lane16 = lane * 16;
     p.n_stages = a.n_stages;
@@ -125,7 +134,7 @@ __device__ __forceinline__ void pipe_start(Pipe& p, const MlpArgs& a, unsigned c
     p.read_off = 0;
     // biases: n_bias_tiles x 32 floats behind the ring
     const float* bsrc = reinterpret_cast<const float*>(a.packed + (size_t)a.n_stages * STAGE_BYTES);
-    float* bdst = reinterpret_cast<float*>(lds + RING_BYTES);
+    float* bdst = reinterpret_cast<float*>(lds);
     for (int i = threadIdx.x; i < a.n_bias_tiles * 32; i += MLP_THREADS) bdst[i] = bsrc[i];
     __syncthreads();
 #pragma unroll
@@ -251,9 +260,10 @@ __device__ __forceinline__ void load_features(const MlpArgs& a, unsigned m, int 
 // ------------------------------------------------------------------------------------------
 // shared by both precisions: bias tile -> accumulator layout
 // ------------------------------------------------------------------------------------------
+// `lds` is the ring base (Pipe::lds)
 __device__ __forceinline__ f32x16 bias_tile(const unsigned char* lds, int tile, int h) {
     // accumulator register r holds output row (r & 3) + 8 (r >> 2) + 4 h
-    const f32x4* b = reinterpret_cast<const f32x4*>(lds + RING_BYTES + tile * BIAS_TILE_BYTES + h * 16);
+    const f32x4* b = reinterpret_cast<const f32x4*>(lds - BIAS_PAD + tile * BIAS_TILE_BYTES + h * 16);
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {

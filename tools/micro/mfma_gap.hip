@@ -29,6 +29,9 @@ __global__ __launch_bounds__(256) void k(const u32x4* g, float* out, unsigned lo
     u32x4 A[16][2], B[16][2];
     for (int i = 0; i < 16; ++i) for (int c = 0; c < 2; ++c) { A[i][c] = g[4096 + (threadIdx.x * 32 + i * 2 + c) % 4096]; B[i][c] = A[i][c]; }
     f32x16 acc[2][2] = {};
+    float side[16];
+    for (int i = 0; i < 16; ++i) side[i] = (float)(threadIdx.x + i) * 0.001f;
+    unsigned sdummy = 0;
     u32x4 q[4];
     for (int kk = 0; kk < 3; ++kk) q[kk] = lds[kk * 64 + lane];
     unsigned long long t0, t1;
@@ -52,9 +55,26 @@ __global__ __launch_bounds__(256) void k(const u32x4* g, float* out, unsigned lo
                     const u32x4 b = V >= 2 ? src[s][c] : src[0][c];
                     cur[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, __builtin_bit_cast(bf16x8, b), cur[c], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (V >= 3 && s >= 1 && s <= 8) {
+                    if ((V == 3 || V == 5 || V == 6) && s >= 1 && s <= 8) {
                         const int sl = (s - 1) * 2 + c, gq = sl >> 2, qd = sl & 3, ct = gq >> 1, half = gq & 1;
-                        dst[2 * (tile & 3) + half][ct][qd] = pack_relu(prv[ct][8 * half + 2 * qd], prv[ct][8 * half + 2 * qd + 1]);
+                        if (V == 5)        // same VALU work on registers that no MFMA touches
+                            dst[2 * (tile & 3) + half][ct][qd] = pack_relu(side[(sl * 2) & 15], side[(sl * 2 + 1) & 15]);
+                        else
+                            dst[2 * (tile & 3) + half][ct][qd] = pack_relu(prv[ct][8 * half + 2 * qd], prv[ct][8 * half + 2 * qd + 1]);
+                        if (V == 6) {      // twice the VALU work
+                            const int sl2 = sl + 16, gq2 = sl2 >> 2, ct2 = gq2 >> 1 & 1, half2 = gq2 & 1;
+                            dst[8 + 2 * (tile & 3) + half2][ct2][qd] = pack_relu(prv[ct2][8 * half2 + 2 * qd], prv[ct2][8 * half2 + 2 * qd + 1]);
+                        }
+                    }
+                    if (V == 4 && c == 1 && s >= 1 && s <= 8) {   // both slices of the k-step after its second MFMA
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc) {
+                            const int sl = (s - 1) * 2 + cc, gq = sl >> 2, qd = sl & 3, ct = gq >> 1, half = gq & 1;
+                            dst[2 * (tile & 3) + half][ct][qd] = pack_relu(prv[ct][8 * half + 2 * qd], prv[ct][8 * half + 2 * qd + 1]);
+                        }
+                    }
+                    if (V == 7 && s >= 1 && s <= 8) {             // scalar ALU work instead of vector ALU work
+                        asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 3" : "+s"(sdummy));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -66,11 +86,12 @@ __global__ __launch_bounds__(256) void k(const u32x4* g, float* out, unsigned lo
     float s = 0;
     for (int t = 0; t < 2; ++t) for (int c = 0; c < 2; ++c) for (int e = 0; e < 16; ++e) s += acc[t][c][e];
     for (int i = 0; i < 16; ++i) for (int c = 0; c < 2; ++c) s += (float)(A[i][c][0] ^ B[i][c][1]);
+    s += side[3] + (float)sdummy;
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-int main() {
+int main(int argc, char** argv) {
     const size_t n = 8192;
     std::vector<unsigned> h(n * 4);
     srand(1);
@@ -83,14 +104,18 @@ int main() {
     hipMalloc(&g, n * 16); hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 8);
     hipMemcpy(g, h.data(), n * 16, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int iters = 3000;
-    for (int rep = 0; rep < 2; ++rep)
-        for (int v = 0; v < 4; ++v) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 3000;
+    for (int rep = 0; rep < 1; ++rep)
+        for (int v = 0; v < 8; ++v) {
             hipEventRecord(e0);
             if (v == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, g, out, cyc, iters);
             if (v == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 0, 0, g, out, cyc, iters);
             if (v == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, g, out, cyc, iters);
             if (v == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(256), 0, 0, g, out, cyc, iters);
+            if (v == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(256), 0, 0, g, out, cyc, iters);
+            if (v == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(256), 0, 0, g, out, cyc, iters);
+            if (v == 6) hipLaunchKernelGGL(k<6>, dim3(256), dim3(256), 0, 0, g, out, cyc, iters);
+            if (v == 7) hipLaunchKernelGGL(k<7>, dim3(256), dim3(256), 0, 0, g, out, cyc, iters);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             unsigned long long hc[256]; hipMemcpy(hc, cyc, sizeof(hc), hipMemcpyDeviceToHost);
