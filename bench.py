@@ -229,7 +229,7 @@ def main():
     dt = time.perf_counter() - t0
     events, hip.MLP_EVENTS = hip.MLP_EVENTS, None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if tdist.get_backend() != "gloo" else "cpu")
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out[:, :3]).all()

@@ -26,6 +26,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        local %= torch.cuda.device_count()      # rehearsals may run several ranks on one GPU (gloo only)
+    backend = backend or os.environ.get("NERF_DIST_BACKEND") or None
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
@@ -85,6 +88,11 @@ def all_gather_rows(local, n_total, per):
     if local.shape[0] < per:
         pad = torch.zeros((per - local.shape[0], width), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 0)
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal on a machine without one GPU per rank: gloo moves host memory
+        host = torch.empty((g * per, width), dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous())
+        return host[:n_total].to(local.device)
     out = torch.empty((g * per, width), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out[:n_total]
@@ -119,7 +127,12 @@ def average_gradients(modules):
     if g == 1 or not params:
         return 0
     flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat = host.to(flat.device)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat /= g
     o = 0
     for p in params:
