@@ -216,7 +216,7 @@ extern "C" int nerf_raw2outputs(const float* raw, int raw_ch, const float* z_val
                                 int d_stride, const float* noise, int R, int S, int white_bkgd,
                                 float* rgb, float* disp, float* acc, float* depth, float* weights,
                                 void* stream) {
-    NERF_REQUIRE(raw && z_vals && d_ptr, "nerf_raw2outputs: null input");
+    NERF_REQUIRE(R == 0 || (raw && z_vals && d_ptr), "nerf_raw2outputs: null input");
     NERF_REQUIRE(raw_ch == 4 || raw_ch == 5, "nerf_raw2outputs: raw_ch must be 4 or 5, got %d", raw_ch);
     NERF_REQUIRE(R >= 0 && S >= 1 && d_stride >= 3, "nerf_raw2outputs: bad shape R=%d S=%d d_stride=%d", R, S, d_stride);
     if (raw_ch == 4) NERF_REQUIRE(((uintptr_t)raw & 15) == 0, "nerf_raw2outputs: raw must be 16-byte aligned");
@@ -248,7 +248,7 @@ extern "C" int nerf_raw2outputs_backward(const float* raw, int raw_ch, const flo
                                          int d_stride, const float* noise, int R, int S, int white_bkgd,
                                          const float* g_rgb, const float* g_disp, const float* g_acc,
                                          const float* g_depth, float* d_raw, void* stream) {
-    NERF_REQUIRE(raw && z_vals && d_ptr && d_raw, "nerf_raw2outputs_backward: null pointer");
+    NERF_REQUIRE(R == 0 || (raw && z_vals && d_ptr && d_raw), "nerf_raw2outputs_backward: null pointer");
     NERF_REQUIRE(raw_ch == 4 || raw_ch == 5, "nerf_raw2outputs_backward: raw_ch must be 4 or 5, got %d", raw_ch);
     NERF_REQUIRE(R >= 0 && S >= 1 && d_stride >= 3, "nerf_raw2outputs_backward: bad shape R=%d S=%d d_stride=%d", R, S, d_stride);
     if (S > 256) {

@@ -571,16 +571,16 @@ extern "C" int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs,
 extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int output_ch, int input_mode,
                                 const float* in0, const float* in1, int R, int S, int ray_cols, float* raw_out,
                                 void* stream) {
-    NERF_REQUIRE(packed && in0 && raw_out, "nerf_mlp_forward: null pointer");
+    NERF_REQUIRE(packed && (R == 0 || (in0 && raw_out)), "nerf_mlp_forward: null pointer");
     NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_F32, "nerf_mlp_forward: unknown precision %d", precision);
     NERF_REQUIRE(R >= 0 && S >= 1, "nerf_mlp_forward: bad shape R=%d S=%d", R, S);
     if (use_viewdirs) NERF_REQUIRE(output_ch == 4, "nerf_mlp_forward: output_ch must be 4 with view directions");
     else NERF_REQUIRE(output_ch == 4 || output_ch == 5, "nerf_mlp_forward: output_ch must be 4 or 5");
     switch (input_mode) {
         case NERF_IN_FEATURES: NERF_REQUIRE(S == 1, "nerf_mlp_forward: feature input is flat (S = 1)"); break;
-        case NERF_IN_POINTS: NERF_REQUIRE(!use_viewdirs || in1, "nerf_mlp_forward: view directions missing"); break;
+        case NERF_IN_POINTS: NERF_REQUIRE(R == 0 || !use_viewdirs || in1, "nerf_mlp_forward: view directions missing"); break;
         case NERF_IN_RAYS:
-            NERF_REQUIRE(in1, "nerf_mlp_forward: z_vals missing");
+            NERF_REQUIRE(R == 0 || in1, "nerf_mlp_forward: z_vals missing");
             NERF_REQUIRE(ray_cols >= (use_viewdirs ? 11 : 8), "nerf_mlp_forward: rays need %d columns, got %d",
                          use_viewdirs ? 11 : 8, ray_cols);
             break;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x,
 using namespace nerf;
 
 extern "C" int nerf_embed(const float* x, long long M, int multires, int include_input, float* out, void* stream) {
-    NERF_REQUIRE(x && out, "nerf_embed: null pointer");
+    NERF_REQUIRE(M == 0 || (x && out), "nerf_embed: null pointer");
     NERF_REQUIRE(M >= 0 && multires >= 0 && multires <= 24, "nerf_embed: bad sizes M=%lld L=%d", M, multires);
     const long long total = M * ((include_input ? 3 : 0) + 6 * multires);
     if (total == 0) return NERF_OK;
@@ -180,7 +180,7 @@ extern "C" int nerf_make_rays(int n_rays, int H, int W, const float* o_in, const
 
 extern "C" int nerf_z_vals(const float* rays, int ray_cols, int R, int S, const float* t_vals,
                            const float* t_rand, int lindisp, float* z_out, void* stream) {
-    NERF_REQUIRE(rays && t_vals && z_out, "nerf_z_vals: null pointer");
+    NERF_REQUIRE(t_vals && (R == 0 || (rays && z_out)), "nerf_z_vals: null pointer");
     NERF_REQUIRE(R >= 0 && S >= 1 && ray_cols >= 8, "nerf_z_vals: bad shape R=%d S=%d cols=%d", R, S, ray_cols);
     if (R == 0) return NERF_OK;
     const size_t total = (size_t)R * S;

@@ -238,7 +238,7 @@ extern "C" int nerf_sample_pdf(const float* bins, int bins_stride, int bins_are_
                                const float* weights, int w_stride, const float* u, int n_u,
                                int u_per_ray, int R, const float* z_vals, int n_z, float* z_samples,
                                int32_t* inds, float* z_sorted, float* z_std, void* stream) {
-    NERF_REQUIRE(bins && weights && u, "nerf_sample_pdf: null input");
+    NERF_REQUIRE(u && (R == 0 || (bins && weights)), "nerf_sample_pdf: null input");
     NERF_REQUIRE(nb >= 2 && n_u >= 1 && R >= 0, "nerf_sample_pdf: bad sizes nb=%d n_u=%d R=%d", nb, n_u, R);
     NERF_REQUIRE(bins_stride >= (bins_are_z ? nb + 1 : nb) && w_stride >= nb - 1,
                  "nerf_sample_pdf: row strides shorter than the rows");

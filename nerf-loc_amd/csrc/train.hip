@@ -466,13 +466,13 @@ extern "C" int nerf_mlp_pack_backward(const float* const* tensors_host, void* pa
 
 extern "C" int nerf_mlp_forward_train(const void* packed, int input_mode, const float* in0, const float* in1, int R,
                                       int S, int ray_cols, float* raw_out, float* tape, void* stream) {
-    NERF_REQUIRE(packed && in0 && raw_out && tape, "nerf_mlp_forward_train: null pointer");
+    NERF_REQUIRE(packed && (R == 0 || (in0 && raw_out && tape)), "nerf_mlp_forward_train: null pointer");
     NERF_REQUIRE(R >= 0 && S >= 1, "nerf_mlp_forward_train: bad shape R=%d S=%d", R, S);
     switch (input_mode) {
         case NERF_IN_FEATURES: NERF_REQUIRE(S == 1, "nerf_mlp_forward_train: feature input is flat (S = 1)"); break;
-        case NERF_IN_POINTS: NERF_REQUIRE(in1, "nerf_mlp_forward_train: view directions missing"); break;
+        case NERF_IN_POINTS: NERF_REQUIRE(R == 0 || in1, "nerf_mlp_forward_train: view directions missing"); break;
         case NERF_IN_RAYS:
-            NERF_REQUIRE(in1, "nerf_mlp_forward_train: z_vals missing");
+            NERF_REQUIRE(R == 0 || in1, "nerf_mlp_forward_train: z_vals missing");
             NERF_REQUIRE(ray_cols >= 11, "nerf_mlp_forward_train: rays need 11 columns, got %d", ray_cols);
             break;
         default: NERF_REQUIRE(false, "nerf_mlp_forward_train: unknown input mode %d", input_mode);

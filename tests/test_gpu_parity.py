@@ -477,3 +477,59 @@ def test_render_bf16_vs_fp32(dev, seed, kind, tol):
     assert err[cond].max() < tol
     assert maxabs(b["acc_map"][cond], f["acc_map"][cond]) < tol
     assert dpsnr < 0.1
+
+
+# ------------------------------------------------------------------ edge cases
+def test_empty_and_single_ray_batches(dev):
+    """Zero rays is a valid call everywhere (the last chunk of a batchify loop can be empty in caller code), and a
+    single ray exercises every partially filled tile."""
+    from nerf_loc_amd import hip, render
+    net = load_net(synth.make_state_dict(3, "B"), dev)
+    f = dict(dtype=torch.float32, device=dev)
+    e = torch.empty((0, 11), **f)
+    assert hip.z_vals(e, 64).shape == (0, 64)
+    assert hip.embed(torch.empty((0, 3), **f), 10).shape == (0, 63)
+    raw = hip.mlp_forward(net.packed_weights(0), 0, True, 4, hip.IN_RAYS, e, torch.empty((0, 64), **f), 0, 64, 11)
+    assert raw.shape == (0, 4)
+    rgb, disp, acc, w, depth = hip.raw2outputs(torch.empty((0, 64, 4), **f), torch.empty((0, 64), **f), e[:, 3:6], 11)
+    assert rgb.shape == (0, 3) and w.shape == (0, 64)
+    zs, _, zsorted, std = hip.sample_pdf(torch.empty((0, 64), **f), torch.empty((0, 62), **f), hip.linspace01(128, dev),
+                                         bins_are_z=True, z_vals=torch.empty((0, 64), **f), want_sorted=True, want_std=True)
+    assert zs.shape == (0, 128) and zsorted.shape == (0, 192) and std.shape == (0,)
+    r = render.render_rays(e, net, _query(dev), 64, N_importance=128, network_fine=net, white_bkgd=True, retraw=True)
+    assert r["rgb_map"].shape == (0, 3) and r["raw"].shape == (0, 192, 4)
+    rays = synth.random_rays(1, seed=9)
+    one = render.render_rays(T(rays, dev), net, _query(dev), 64, N_importance=128, network_fine=net, white_bkgd=True)
+    o = orc.render_rays(rays, synth.make_state_dict(3, "B"), 64, 128, sd_fine=synth.make_state_dict(3, "B"), white_bkgd=True)
+    assert maxabs(N(one["rgb0"]), o["rgb0"]) < 1e-4 and maxabs(N(one["acc0"]), o["acc0"]) < 1e-4
+
+
+def test_chunking_does_not_change_results(dev):
+    """batchify_rays / netchunk only bound memory: any chunking gives bit-identical maps (run_nerf.py:54-66)."""
+    from nerf_loc_amd import render
+    rays = T(synth.random_rays(1000, seed=12), dev)
+    nc, nf = load_net(synth.make_state_dict(5, "B"), dev), load_net(synth.make_state_dict(6, "B"), dev)
+    kw = dict(network_fn=nc, network_query_fn=_query(dev), N_samples=64, N_importance=128, network_fine=nf,
+              white_bkgd=True, retraw=True)
+    whole = render.batchify_rays(rays, 1 << 20, **kw)
+    parts = render.batchify_rays(rays, 77, **kw)
+    for k in whole:
+        assert torch.equal(whole[k], parts[k]) or (torch.isnan(whole[k]) == torch.isnan(parts[k])).all() and \
+            torch.equal(torch.nan_to_num(whole[k]), torch.nan_to_num(parts[k])), k
+
+
+def test_invalid_arguments_raise(dev):
+    from nerf_loc_amd import hip, render
+    net = load_net(synth.make_state_dict(3, "B"), dev)
+    rays = T(synth.random_rays(8, seed=1), dev)
+    with pytest.raises(ValueError):
+        render.render_rays(rays[:, :5], net, _query(dev), 64)
+    with pytest.raises(ValueError):
+        hip.raw2outputs(torch.zeros(4, 8, 4, device=dev), torch.zeros(4, 9, device=dev), rays[:, 3:6], 11)
+    with pytest.raises(ValueError):
+        hip.sample_pdf(torch.zeros(4, 9, device=dev), torch.zeros(4, 9, device=dev), hip.linspace01(4, dev))
+    with pytest.raises(hip.NerfHipError):
+        hip.mlp_forward(net.packed_weights(0), 0, True, 4, hip.IN_RAYS, rays[:, :8].contiguous(),
+                        torch.zeros(8, 4, device=dev), 8, 4, 8)          # view directions missing from the ray rows
+    with pytest.raises(ValueError):
+        hip.z_vals(rays.double(), 8)
