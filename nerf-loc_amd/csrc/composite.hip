@@ -14,49 +14,70 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <int RAW_CH>
+// sigmoid and 1 - exp(-x) through the hardware exp2 / rcp units (about 1 ulp each): the maps are compared at
+// 1e-4 against the reference, nothing here is part of a bit-exact contract.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_exp_neg(float x) {   // exp(-x)
+    return __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
+}
+
+// NCH chunks of 64 samples, all loaded before the first scan so that a wave keeps NCH x 24 B per lane in flight.
+// A wavefront takes RPW consecutive rays (unrolled, so the loads of all of them are in flight together).
+template <int RAW_CH, int NCH, int RPW>
 __global__ __launch_bounds__(256) void raw2outputs_kernel(
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ d_ptr,
     int d_stride, const float* __restrict__ noise, int R, int S, int white_bkgd,
     float* __restrict__ rgb_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
     float* __restrict__ depth_out, float* __restrict__ weights_out) {
     const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (ray >= R) return;  // whole wave leaves together
-
-    const float* dp = d_ptr + (size_t)ray * d_stride;
-    const float dx = dp[0], dy = dp[1], dz = dp[2];
-    const float dnorm = sqrtf(fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz)));
+    const int ray0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW;
+#pragma unroll
+    for (int rq = 0; rq < RPW; ++rq) {
+    const int ray = ray0 + rq;
+    if (ray >= R) break;   // whole wave leaves together
 
     const float* zr = z_vals + (size_t)ray * S;
     const float* rr = raw + (size_t)ray * S * RAW_CH;
     const float* nr = noise ? noise + (size_t)ray * S : nullptr;
+    const float* dp = d_ptr + (size_t)ray * d_stride;
 
+    const float dx = dp[0], dy = dp[1], dz = dp[2];
+    const float dnorm = sqrtf(fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz)));
     float carry = 1.0f;                    // product of (1-alpha+1e-10) over all earlier chunks
     float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_depth = 0.f, s_acc = 0.f;
-    for (int base = 0; base < S; base += WAVE) {
-        const int i = base + lane;
+    for (int base = 0; base < S; base += 64 * NCH) {    // one trip unless S > 64 NCH
+    float r0[NCH], r1[NCH], r2[NCH], r3[NCH], zc[NCH], zn[NCH], nz[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int i = base + 64 * k + lane;
+        const int ic = i < S ? i : S - 1;
+        if (RAW_CH == 4) {
+            const float4 q = reinterpret_cast<const float4*>(rr)[ic];
+            r0[k] = q.x; r1[k] = q.y; r2[k] = q.z; r3[k] = q.w;
+        } else {
+            const float* q = rr + (size_t)ic * RAW_CH;
+            r0[k] = q[0]; r1[k] = q[1]; r2[k] = q[2]; r3[k] = q[3];
+        }
+        zc[k] = zr[ic];
+        zn[k] = zr[ic + 1 < S ? ic + 1 : S - 1];
+        nz[k] = nr ? nr[ic] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int i = base + 64 * k + lane;
         const bool valid = i < S;
         float alpha = 0.f, z = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
         if (valid) {
-            float r0, r1, r2, r3;
-            if (RAW_CH == 4) {
-                const float4 q = reinterpret_cast<const float4*>(rr)[i];
-                r0 = q.x; r1 = q.y; r2 = q.z; r3 = q.w;
-            } else {
-                const float* q = rr + (size_t)i * RAW_CH;
-                r0 = q[0]; r1 = q[1]; r2 = q[2]; r3 = q[3];
-            }
-            z = zr[i];
+            z = zc[k];
             // dists = [z[1:]-z[:-1], 1e10] * |d|
-            const float dist = fmul((i + 1 < S) ? fsub(zr[i + 1], z) : 1e10f, dnorm);
-            float sig = r3;
-            if (nr) sig = fadd(sig, nr[i]);
-            sig = fmaxf(sig, 0.0f);
-            alpha = fsub(1.0f, expf(-fmul(sig, dist)));
-            c0 = fdiv(1.0f, fadd(1.0f, expf(-r0)));
-            c1 = fdiv(1.0f, fadd(1.0f, expf(-r1)));
-            c2 = fdiv(1.0f, fadd(1.0f, expf(-r2)));
+            const float dist = fmul((i + 1 < S) ? fsub(zn[k], z) : 1e10f, dnorm);
+            const float sig = fmaxf(fadd(r3[k], nz[k]), 0.0f);
+            alpha = fsub(1.0f, fast_exp_neg(fmul(sig, dist)));
+            c0 = fast_sigmoid(r0[k]);
+            c1 = fast_sigmoid(r1[k]);
+            c2 = fast_sigmoid(r2[k]);
         }
         // inclusive product scan of (1 - alpha + 1e-10) over the wave, made exclusive by a shift
         const float one_m = fadd(fsub(1.0f, alpha), 1e-10f);
@@ -76,6 +97,7 @@ __global__ __launch_bounds__(256) void raw2outputs_kernel(
         s_depth += w * z;
         s_acc += w;
     }
+    }
     s_r = wave_sum(s_r); s_g = wave_sum(s_g); s_b = wave_sum(s_b);
     s_depth = wave_sum(s_depth); s_acc = wave_sum(s_acc);
     if (lane == 0) {
@@ -93,6 +115,7 @@ __global__ __launch_bounds__(256) void raw2outputs_kernel(
         }
         if (acc_out) acc_out[ray] = s_acc;
         if (depth_out) depth_out[ray] = s_depth;
+    }
     }
 }
 
@@ -221,14 +244,23 @@ extern "C" int nerf_raw2outputs(const float* raw, int raw_ch, const float* z_val
     NERF_REQUIRE(R >= 0 && S >= 1 && d_stride >= 3, "nerf_raw2outputs: bad shape R=%d S=%d d_stride=%d", R, S, d_stride);
     if (raw_ch == 4) NERF_REQUIRE(((uintptr_t)raw & 15) == 0, "nerf_raw2outputs: raw must be 16-byte aligned");
     if (R == 0) return NERF_OK;
-    const int rays_per_block = 4;
-    dim3 grid((R + rays_per_block - 1) / rays_per_block), block(rays_per_block * WAVE);
-    if (raw_ch == 4)
-        hipLaunchKernelGGL(raw2outputs_kernel<4>, grid, block, 0, as_stream(stream), raw, z_vals, d_ptr, d_stride,
-                           noise, R, S, white_bkgd, rgb, disp, acc, depth, weights);
-    else
-        hipLaunchKernelGGL(raw2outputs_kernel<5>, grid, block, 0, as_stream(stream), raw, z_vals, d_ptr, d_stride,
-                           noise, R, S, white_bkgd, rgb, disp, acc, depth, weights);
+    const int nch = (S + 63) / 64;
+    const int rpw = nch == 1 ? 4 : nch == 2 ? 2 : 1;
+    const int rays_per_block = 4 * rpw;
+    dim3 grid((R + rays_per_block - 1) / rays_per_block), block(4 * WAVE);
+#define NERF_R2O_FWD(CH, n, q)                                                                                       \
+    hipLaunchKernelGGL((raw2outputs_kernel<CH, n, q>), grid, block, 0, as_stream(stream), raw, z_vals, d_ptr, d_stride, \
+                       noise, R, S, white_bkgd, rgb, disp, acc, depth, weights)
+#define NERF_R2O_SWITCH(CH)                                                                  \
+    switch (nch) {                                                                           \
+        case 1: NERF_R2O_FWD(CH, 1, 4); break;                                               \
+        case 2: NERF_R2O_FWD(CH, 2, 2); break;                                               \
+        case 3: NERF_R2O_FWD(CH, 3, 1); break;                                               \
+        default: NERF_R2O_FWD(CH, 4, 1); break;                                              \
+    }
+    if (raw_ch == 4) { NERF_R2O_SWITCH(4) } else { NERF_R2O_SWITCH(5) }
+#undef NERF_R2O_SWITCH
+#undef NERF_R2O_FWD
     NERF_LAUNCH_CHECK();
     return NERF_OK;
 }
