@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W [--precision bf16|fp32] [--res 800]
 
-One step = one full render of the BASELINE.json configuration 2 workload on every rank: an 800 x 800 view
+One step = one full render of the reference's headline workload on every rank: an 800 x 800 view
 (640 000 rays), 64 coarse + 128 importance samples, D=8/W=256 networks with view directions, separate fine
 network, random-init weights ("trained-like" scaling so the scene is opaque), white background.  Rays are
 generated on the device from the pose; inputs and weights are resident in HBM before the timed region.  With
@@ -89,7 +89,7 @@ def pmc_traffic(precision):
 
 
 def build_objects(device, precision, n_objects):
-    """BASELINE configuration 4: per-object networks rendering the detector's inputs.  Each object: 8 poses x 2
+    """Per-object networks rendering the detector's inputs.  Each object: 8 poses x 2
     focal lengths (fine K and K/1.2) at 240 x 180, 64 samples, coarse network only, raw volume kept
     (model_3detr.py:619-724 through nerf_utils.render_path)."""
     import types
@@ -269,7 +269,8 @@ def main():
                                        else "data parallel x%d, 1 gradient all-reduce" % world)},
             "roofline": roof,
         }
-        line["cpu_baseline"] = None if (args.no_cpu_baseline or args.workload != "view") else cpu_baseline()
+        # the CPU figure is reported once, by the single-GPU run
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or args.workload != "view" or world > 1) else cpu_baseline()
         print(json.dumps(line))
     if world > 1:
         tdist.barrier()

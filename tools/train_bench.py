@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the training iteration of BASELINE configuration 5 on one GPU: 4096 rays, 64 + 128 samples, stratified
+"""Times the reference's training iteration on one GPU: 4096 rays, 64 + 128 samples, stratified
 jitter, forward + backward through both networks + Adam (run_nerf.py:770-796).  Prints ms/iteration and rays/s."""
 import argparse
 import json
