@@ -5,3 +5,4 @@ from run_nerf_helpers import *  # noqa: F401,F403  (the reference does the same,
 from nerf_loc_amd.render import (batchify, run_network, batchify_rays, render, render_path, create_nerf,  # noqa: F401
                                  raw2outputs, render_rays, load_checkpoint, save_checkpoint)
 from nerf_loc_amd.train import train_step  # noqa: F401
+from nerf_loc_amd.raybank import RayBank  # noqa: F401

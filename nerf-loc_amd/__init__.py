@@ -9,7 +9,7 @@ import importlib
 
 __version__ = "0.1.0"
 
-_LAZY = ("synth", "hip", "helpers", "render", "nerf_utils", "dist", "train")
+_LAZY = ("synth", "hip", "helpers", "render", "nerf_utils", "dist", "train", "raybank")
 
 
 def __getattr__(name):

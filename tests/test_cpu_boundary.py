@@ -201,3 +201,33 @@ def test_dropin_alias_modules_resolve_to_the_engine():
             "print('ALIAS OK')\n") % os.path.join(ROOT, "dropin")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
     assert "ALIAS OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_ray_bank_batching_mode_follows_the_reference_draws():
+    """use_batching=True (run_nerf.py:688-737) is host + indexing logic: same numpy shuffle, same epoch handling."""
+    from nerf_loc_amd import raybank
+    H, W = 6, 5
+    K = np.array([[7.0, 0, 2.5], [0, 7.0, 3.0], [0, 0, 1]])
+    rs = np.random.RandomState(0)
+    images = rs.uniform(size=(4, H, W, 3)).astype(np.float32)
+    poses = np.stack([synth.pose_spherical(30.0 * i, -30.0, 4.0)[:3, :4] for i in range(4)]).astype(np.float32)
+    i_train = [0, 2, 3]
+    np.random.seed(5)
+    bank = raybank.RayBank(images, poses, H, W, K, i_train, N_rand=32, use_batching=True, device="cpu")
+    # restatement of the reference's preparation with the same seed
+    np.random.seed(5)
+    rays = np.stack([helpers.get_rays_np(H, W, K, p) for p in poses[:, :3, :4]], 0)
+    ref = np.transpose(np.concatenate([rays, images[:, None]], 1), [0, 2, 3, 1, 4])
+    ref = np.reshape(np.stack([ref[i] for i in i_train], 0), [-1, 3, 3]).astype(np.float32)
+    np.random.shuffle(ref)
+    assert len(bank) == 3 * H * W == ref.shape[0]
+    b, t = bank.next(1)
+    assert tuple(b.shape) == (2, 32, 3) and tuple(t.shape) == (32, 3)
+    assert np.array_equal(b.numpy(), np.transpose(ref[:32], [1, 0, 2])[:2]) and np.array_equal(t.numpy(), ref[:32, 2])
+    bank.next(2)
+    torch.manual_seed(3)
+    b3, _ = bank.next(3)            # 64..96 of 90 rows: short last batch, then the epoch reshuffle
+    assert b3.shape[1] == 90 - 64 and bank.i_batch == 0
+    torch.manual_seed(3)
+    perm = torch.randperm(90)
+    assert np.array_equal(bank.rays_rgb.numpy(), ref[perm.numpy()])

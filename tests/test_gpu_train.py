@@ -220,3 +220,33 @@ def test_optimisation_reduces_the_loss(dev):
     print("losses:", " ".join("%.4f" % l for l in losses))
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     assert abs(opt.param_groups[0]["lr"] - 5e-4 * 0.1 ** (12 / 250000.0)) < 1e-12
+
+
+def test_ray_bank_single_image_mode(dev):
+    """use_batching=False (run_nerf.py:739-768): image choice, centre crop and pixel choice with the reference's
+    numpy draws; rays come from the device kernel."""
+    from nerf_loc_amd import raybank
+    H, W = 20, 16
+    K = np.array([[25.0, 0, 8.0], [0, 25.0, 10.0], [0, 0, 1]])
+    rs = np.random.RandomState(1)
+    images = rs.uniform(size=(3, H, W, 3)).astype(F32)
+    poses = np.stack([synth.pose_spherical(40.0 * i, -30.0, 4.0)[:3, :4] for i in range(3)]).astype(F32)
+    i_train = [0, 2]
+    bank = raybank.RayBank(images, poses, H, W, K, i_train, N_rand=24, use_batching=False, precrop_iters=5,
+                           precrop_frac=0.5, device=dev)
+    for it, crop in ((1, True), (7, False)):
+        np.random.seed(100 + it)
+        b, t = bank.next(it)
+        np.random.seed(100 + it)
+        img_i = np.random.choice(i_train)
+        if crop:
+            dH, dW = int(H // 2 * 0.5), int(W // 2 * 0.5)
+            rr, cc = np.meshgrid(np.arange(H // 2 - dH, H // 2 + dH), np.arange(W // 2 - dW, W // 2 + dW), indexing="ij")
+        else:
+            rr, cc = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        coords = np.stack([rr, cc], -1).reshape(-1, 2)
+        sel = coords[np.random.choice(coords.shape[0], size=[24], replace=False)]
+        o, d = orc.get_rays(H, W, K, poses[img_i])
+        assert tuple(b.shape) == (2, 24, 3)
+        assert np.abs(N(b[0]) - o[sel[:, 0], sel[:, 1]]).max() < 1e-6 and np.abs(N(b[1]) - d[sel[:, 0], sel[:, 1]]).max() < 1e-6
+        assert np.array_equal(N(t), images[img_i][sel[:, 0], sel[:, 1]])
