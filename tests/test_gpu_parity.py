@@ -533,3 +533,45 @@ def test_invalid_arguments_raise(dev):
                         torch.zeros(8, 4, device=dev), 8, 4, 8)          # view directions missing from the ray rows
     with pytest.raises(ValueError):
         hip.z_vals(rays.double(), 8)
+
+
+# ------------------------------------------------------------------ full size, size-independent properties
+def test_full_size_view_properties(dev):
+    """The 800 x 800, 64 + 128 workload of the benchmark (640 000 rays) in float32 mode: what must hold at any size
+    (sortedness and permutation property of the merged depths, weights summing to acc, value ranges, independence
+    of how the rays are split), plus a random sample of rays against the oracle."""
+    from nerf_loc_amd import hip, render
+    H, W, K, c2w, near, far = synth.lego_camera(800, theta=30.0)
+    sc, sf = synth.make_state_dict(0, "B"), synth.make_state_dict(1, "B")
+    nc, nf = load_net(sc, dev), load_net(sf, dev)
+    rays, _ = render._build_rays(H, W, K, None, T(c2w.astype(F32), dev), False, near, far, True, None)
+    assert rays.shape == (640000, 11)
+    kw = dict(network_fn=nc, network_query_fn=_query(dev), N_samples=64, N_importance=128, network_fine=nf,
+              white_bkgd=True)
+    whole = render.batchify_rays(rays, 1 << 20, **kw)
+    # (1) any split of the ray batch gives bit-identical maps
+    lo = render.batchify_rays(rays[:333333], 1 << 20, **kw)
+    hi = render.batchify_rays(rays[333333:], 100000, **kw)
+    for k in ("rgb_map", "acc_map", "rgb0", "acc0", "z_std"):
+        assert torch.equal(whole[k], torch.cat([lo[k], hi[k]], 0)), k
+    # (2) ranges
+    assert float(whole["acc_map"].min()) >= 0 and float(whole["acc_map"].max()) <= 1 + 1e-5
+    assert float(whole["rgb_map"].min()) >= -1e-5 and float(whole["rgb_map"].max()) <= 1 + 2e-5
+    assert torch.isfinite(whole["rgb_map"]).all() and torch.isfinite(whole["z_std"]).all()
+    # (3) the stages on the full batch: weights sum to acc; merged depths are sorted and a permutation of the inputs
+    z = hip.z_vals(rays, 64)
+    raw = hip.mlp_forward(nc.packed_weights(0), 0, True, 4, hip.IN_RAYS, rays, z, 640000, 64, 11).reshape(640000, 64, 4)
+    rgb0, _, acc0, w0, depth0 = hip.raw2outputs(raw, z, rays[:, 3:6], 11, None, True)
+    assert float((w0.sum(-1) - acc0).abs().max()) < 2e-6 and float(w0.min()) >= 0
+    assert torch.equal(rgb0, whole["rgb0"])
+    zs, inds, zsorted, std = hip.sample_pdf(z, w0[:, 1:-1], hip.linspace01(128, dev), bins_are_z=True, z_vals=z,
+                                            want_inds=True, want_sorted=True, want_std=True)
+    assert bool((zsorted[:, 1:] >= zsorted[:, :-1]).all())
+    assert torch.equal(torch.sort(torch.cat([z, zs], -1), -1)[0], zsorted)
+    assert int(inds.min()) >= 1 and int(inds.max()) <= 63
+    assert bool((zs >= z[:, :1]).all()) and bool((zs <= z[:, -1:]).all())
+    # (4) a random sample of rays against the oracle (coarse pass exactly comparable)
+    rs = np.random.RandomState(0)
+    pick = rs.choice(640000, 96, replace=False)
+    o = orc.render_rays(N(rays[pick]), sc, 64, 0, white_bkgd=True)
+    assert maxabs(N(whole["rgb0"][pick]), o["rgb_map"]) < 1e-4 and maxabs(N(whole["acc0"][pick]), o["acc_map"]) < 1e-4
