@@ -103,9 +103,6 @@ __device__ __forceinline__ void tile_bf16(Stream& st, int pos, int h, int bias_n
         st.tick(k);
         __builtin_amdgcn_sched_barrier(0);
         st.fetch(k + PF);
-#ifdef NERF_EXP_NOP
-        asm volatile("s_nop 7\n\ts_nop 7");
-#endif
         if (s == KS / 2) bias_next = bias_tile(st.p.lds, bias_next_idx, h);
         __builtin_amdgcn_sched_barrier(0);
         const u32x4* b = s < KPE ? pe[s] : (s < KPE + KH ? hin[s - KPE] : vw[s - KPE - KH]);

@@ -98,10 +98,8 @@ struct Pipe {
     // Issue one more stage, then make the oldest outstanding one visible to the workgroup.
     __device__ __forceinline__ void advance() {
         issue();
-#ifndef NERF_EXP_NOBARRIER
         asm volatile("s_waitcnt vmcnt(" NERF_VMCNT_KEEP ")" ::: "memory");
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void next_stage() {
