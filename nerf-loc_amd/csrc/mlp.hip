@@ -59,15 +59,15 @@ struct Stream {                              // position-independent view of the
 };
 
 __device__ __forceinline__ unsigned pack_pair(float a, float b, bool relu) {
+    if (relu) {
+        // Activations are stored scaled into [0, 1) (mlp_layout.h, scale_kernel): the clamp bit of the conversion
+        // (saturate to [0, 1], negatives and -0 to +0) is then ReLU, at no extra instruction.
+        unsigned r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
     const f32x2 f = {a, b};
     const bf16x2 v = __builtin_convertvector(f, bf16x2);   // one v_cvt_pk_bf16_f32
-    if (relu) {
-        // relu on the packed pair: as signed 16-bit integers every negative bf16 is < 0
-        s16x2 i = __builtin_bit_cast(s16x2, v);
-        const s16x2 z = {0, 0};
-        i = __builtin_elementwise_max(i, z);
-        return __builtin_bit_cast(unsigned, i);
-    }
     return __builtin_bit_cast(unsigned, v);
 }
 
@@ -384,6 +384,41 @@ __device__ __forceinline__ const float* pack_row(const PackArgs& a, const LayerD
     }
 }
 
+// Output scales of the bf16 network, one block.  B_l bounds |pre-activation| of layer l for any input with
+// |feature| <= INPUT_BOUND: B_l = max_row (|b| + sum_j |W_j| * bound of input j).  The stored activations are
+// s_l * relu(.) with s_l = 2^-ceil(log2(2 B_l)) < 1 / (2 B_l): the factor 2 covers the bf16 rounding of weights
+// and activations.  Powers of two commute with every rounding step, so the network's results do not change.
+__global__ __launch_bounds__(256) void scale_kernel(PackArgs a, float* scales) {
+    __shared__ float red[256];
+    __shared__ float bound[MAX_LAYERS];
+    for (int li = 0; li < a.net.n_layers; ++li) {
+        const LayerDesc& L = a.net.layer[li];
+        const float bin = L.src_layer >= 0 ? bound[L.src_layer] : 0.0f;
+        float m = 0.0f;
+        for (int row = threadIdx.x; row < L.out_dim; row += 256) {
+            const float* W = a.t[L.w_idx] + (size_t)row * L.in_dim;
+            float sum = fabsf(a.t[L.b_idx][row]);
+            for (int col = 0; col < L.in_dim; ++col) {
+                const bool hid = col >= L.hid_col && col < L.hid_col + L.hid_feats;
+                sum += fabsf(W[col]) * (hid ? bin : INPUT_BOUND);
+            }
+            m = fmaxf(m, sum);
+        }
+        red[threadIdx.x] = m;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float B = fmaxf(red[0], 1e-30f);
+            bound[li] = B;
+            scales[li] = (a.bf16 && L.scaled_out) ? exp2f(-ceilf(log2f(2.0f * B))) : 1.0f;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int F = gid >> 6, lane = gid & 63;
@@ -405,6 +440,15 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
         int row;
         const float* W = pack_row(a, L, tile, r, false, row);
         const int n_el = a.bf16 ? 8 : 4;
+        // bf16: weights carry (scale of the tile's output) / (scale of the k part's input)
+        const float* scales = reinterpret_cast<const float*>(a.out + (size_t)a.padded_frags * FRAG_BYTES +
+                                                             (size_t)a.net.n_bias_tiles * BIAS_TILE_BYTES);
+        float s_out = 1.0f, s_hid = 1.0f;
+        if (a.bf16) {
+            const bool head_row = L.kind == LK_FEATURE_ALPHA && tile == 8;
+            s_out = (L.scaled_out && !head_row) ? scales[li] : 1.0f;
+            s_hid = L.src_layer >= 0 ? scales[L.src_layer] : 1.0f;
+        }
         float vals[8];
         for (int j = 0; j < n_el; ++j) {
             int col = -1;
@@ -439,6 +483,10 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
                 continue;
             }
             vals[j] = (W && col >= 0) ? W[(size_t)row * L.in_dim + col] : 0.0f;
+            if (a.bf16) {
+                const int npe = L.has_pe ? 4 : 0, nh = L.hid_feats / 16;
+                vals[j] *= (g >= npe && g < npe + nh) ? s_out / s_hid : s_out;
+            }
         }
         unsigned char* dst = a.out + (size_t)F * FRAG_BYTES + lane * 16;
         if (a.bf16) {
@@ -461,7 +509,15 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
         }
         int row;
         const float* Bp = pack_row(a, a.net.layer[li], t, rr, true, row);
-        reinterpret_cast<float*>(a.out + (size_t)a.padded_frags * FRAG_BYTES)[bi] = Bp ? Bp[row] : 0.0f;
+        float v = Bp ? Bp[row] : 0.0f;
+        if (a.bf16) {
+            const LayerDesc& L = a.net.layer[li];
+            const float* scales = reinterpret_cast<const float*>(a.out + (size_t)a.padded_frags * FRAG_BYTES +
+                                                                 (size_t)a.net.n_bias_tiles * BIAS_TILE_BYTES);
+            const bool head_row = L.kind == LK_FEATURE_ALPHA && t == 8;
+            if (L.scaled_out && !head_row) v *= scales[li];
+        }
+        reinterpret_cast<float*>(a.out + (size_t)a.padded_frags * FRAG_BYTES)[bi] = v;
     }
 }
 
@@ -500,6 +556,12 @@ __global__ void selftest_kernel(int* bad) {
 }
 
 int launch_pack(const PackArgs& a, hipStream_t stream) {
+    if (a.bf16) {   // output scales first: the pack kernel reads them from behind the bias block
+        float* scales = reinterpret_cast<float*>(a.out + (size_t)a.padded_frags * FRAG_BYTES +
+                                                 (size_t)a.net.n_bias_tiles * BIAS_TILE_BYTES);
+        hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(256), 0, stream, a, scales);
+        NERF_LAUNCH_CHECK();
+    }
     const int threads = a.padded_frags * 64 + a.net.n_bias_tiles * 32;
     hipLaunchKernelGGL(pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, a);
     NERF_LAUNCH_CHECK();
@@ -540,7 +602,7 @@ static int frag_total(int precision, int use_viewdirs) {
 extern "C" size_t nerf_mlp_packed_bytes(int precision, int use_viewdirs) {
     if (precision != NERF_PREC_BF16 && precision != NERF_PREC_F32) return 0;
     return (size_t)frag_total(precision, use_viewdirs) * FRAG_BYTES +
-           (size_t)(use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD) * BIAS_TILE_BYTES;
+           (size_t)(use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD) * BIAS_TILE_BYTES + SCALE_BYTES;
 }
 
 extern "C" int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs, int output_ch, int precision,

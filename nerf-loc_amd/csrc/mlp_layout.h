@@ -54,6 +54,10 @@ struct LayerDesc {
     // optional extra k part of `extra_frags` float32 fragments taken from the transposed tensor w2_idx
     // (row stride in_dim2, rows c < k_limit2): the density head joining the feature head's input gradient
     int extra_frags, in_dim2, k_limit2;
+    // bf16 kernel only: outputs of a layer are kept multiplied by a power of two chosen at pack time so that they
+    // provably stay below 1; v_cvt_pk_bf16_f32 with the clamp bit (saturate to [0, 1]) is then exactly ReLU.
+    int src_layer;    // layer whose (scaled) output is this layer's hidden k part, -1: none
+    int scaled_out;   // 1: the main rows of this layer are stored scaled (hidden layers, feature, view layer)
 };
 
 struct NetDesc {
@@ -95,25 +99,30 @@ inline NetDesc make_net_desc(bool use_viewdirs, int output_ch) {
         L.w_idx = 2 * i; L.b_idx = 2 * i + 1; L.w2_idx = L.b2_idx = -1;
         L.in_dim = (i == 0) ? 63 : (i == 5 ? 319 : 256);
         L.pe_col = 0; L.hid_col = (i == 5) ? 63 : 0; L.view_col = 0;
+        L.src_layer = i - 1; L.scaled_out = 1;
         n.layer[li++] = L; bt += L.n_tiles;
     }
     if (use_viewdirs) {
         LayerDesc fa{};
         fa.kind = LK_FEATURE_ALPHA; fa.n_tiles = 9; fa.out_dim = 256; fa.hid_feats = 256;
         fa.w_idx = 18; fa.b_idx = 19; fa.w2_idx = 20; fa.b2_idx = 21; fa.in_dim = 256;
+        fa.src_layer = 7; fa.scaled_out = 1;      // the feature rows; the density row is a network output (scale 1)
         n.layer[li++] = fa; bt += fa.n_tiles;
         LayerDesc vw{};
         vw.kind = LK_HIDDEN; vw.n_tiles = 4; vw.out_dim = 128; vw.hid_feats = 256; vw.has_view = 1;
         vw.w_idx = 16; vw.b_idx = 17; vw.w2_idx = vw.b2_idx = -1; vw.in_dim = 283; vw.view_col = 256;
+        vw.src_layer = 8; vw.scaled_out = 1;
         n.layer[li++] = vw; bt += vw.n_tiles;
         LayerDesc rgb{};
         rgb.kind = LK_RGB; rgb.n_tiles = 1; rgb.out_dim = 3; rgb.hid_feats = 128;
         rgb.w_idx = 22; rgb.b_idx = 23; rgb.w2_idx = rgb.b2_idx = -1; rgb.in_dim = 128;
+        rgb.src_layer = 9; rgb.scaled_out = 0;
         n.layer[li++] = rgb; bt += rgb.n_tiles;
     } else {
         LayerDesc o{};
         o.kind = LK_OUTPUT; o.n_tiles = 1; o.out_dim = output_ch; o.hid_feats = 256;
         o.w_idx = 18; o.b_idx = 19; o.w2_idx = o.b2_idx = -1; o.in_dim = 256;
+        o.src_layer = 7; o.scaled_out = 0;
         n.layer[li++] = o; bt += o.n_tiles;
     }
     n.n_layers = li;
@@ -132,7 +141,7 @@ inline NetDesc make_backward_desc() {
         LayerDesc L{};
         L.kind = LK_HIDDEN; L.n_tiles = tiles; L.out_dim = out_dim; L.hid_feats = kfeats;
         L.w_idx = w_idx; L.b_idx = -1; L.w2_idx = L.b2_idx = -1; L.in_dim = in_dim;
-        L.trans = 1; L.row_off = row_off; L.k_limit = k_limit;
+        L.trans = 1; L.row_off = row_off; L.k_limit = k_limit; L.src_layer = -1;
         n.layer[li] = L;
         return n.layer[li++];
     };
@@ -162,6 +171,8 @@ constexpr int FRAGS_F32_NOVD = 8 * 8 + 4 * 8 * 32 + 8 * 40 + 2 * 8 * 32 + 32;   
 constexpr int BIAS_TILES_VD = 64 + 9 + 4 + 1;    // 78
 constexpr int BIAS_TILES_NOVD = 64 + 1;          // 65
 constexpr int BIAS_TILE_BYTES = 32 * 4;
+constexpr int SCALE_BYTES = 64;                  // MAX_LAYERS output scales behind the bias block (pack-time scratch)
+constexpr float INPUT_BOUND = 16777216.0f;       // |network input| assumed <= 2^24 when the scales are chosen
 
 static_assert(FRAGS_BF16_VD % STAGE_FRAGS == 0 && FRAGS_BF16_NOVD % STAGE_FRAGS == 0, "stage-aligned");
 static_assert(FRAGS_F32_VD % STAGE_FRAGS == 0 && FRAGS_F32_NOVD % STAGE_FRAGS == 0, "stage-aligned");

@@ -75,10 +75,11 @@ def test_library_loads_and_exports_every_symbol():
 def test_packed_sizes_host_only():
     lib = hip.lib()
     frag, bias = 1024, 128
-    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 1) == 1184 * frag + 78 * bias
-    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 0) == 976 * frag + 65 * bias
-    assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 1) == 2368 * frag + 78 * bias
-    assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 0) == 1952 * frag + 65 * bias
+    scales = 64          # pack-time scratch behind the bias block
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 1) == 1184 * frag + 78 * bias + scales
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 0) == 976 * frag + 65 * bias + scales
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 1) == 2368 * frag + 78 * bias + scales
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 0) == 1952 * frag + 65 * bias + scales
 
 
 def test_invalid_arguments_are_refused_before_any_launch():
