@@ -163,3 +163,56 @@ def render_path_device(render_poses, hwf, K, render_kwargs, render_factor=0):
     P = len(render_poses)
     shp = lambda t: None if t is None else t.reshape([P, H, W] + list(t.shape[1:]))
     return shp(ret['rgb_map']), shp(ret.get('disp_map')), shp(ret.get('raw')), shp(ret.get('depth_map'))
+
+
+_DEPTH_TYPES = ('rendered_depth', 'nerf_rendered_depth', 'nerf_rendered_rgb_rendered_depth', 'rendered_rgb_rendered_depth')
+
+
+def _assemble(input_type, rgbs, depths, raws, depths_for_plain_depth):
+    """The per-input_type tensor the detector consumes (model_3detr.py:657-670 / 699-712)."""
+    if input_type == 'rendered_rgb':
+        return rgbs
+    if input_type == 'rendered_depth':
+        return depths_for_plain_depth[..., None]
+    rgb4 = rgbs[..., None].expand(*rgbs.shape, 4)                      # np.repeat(rgbs[..., None], 4, -1)
+    dep4 = depths[..., None, None].expand(*depths.shape, 1, 4)          # np.repeat(disps[..., None, None], 4, -1)
+    if input_type == 'nerf_rendered_rgb':
+        return torch.cat((raws, rgb4), -2)
+    if input_type == 'nerf_rendered_depth':
+        return torch.cat((raws, dep4), -2)
+    if input_type == 'nerf_rendered_rgb_rendered_depth':
+        return torch.cat((raws, rgb4, dep4), -2)
+    if input_type == 'rendered_rgb_rendered_depth':
+        return torch.cat((rgb4, dep4), -2)
+    return raws                                                         # 'nerf': the raw volume itself
+
+
+def detector_inputs(poses, render_kwargs, input_type='nerf', focal_length=None):
+    """What Model3DETR.forward builds from one scan before its backbone runs (model_3detr.py:619-724), kept on the
+    device: poses [..., 3, 5] (LLFF layout, last column = H, W, focal) -> dict with
+      'raws'         [P, H, W, S(+3|+1|+4), 4] (or the rgb / depth maps, by input_type),
+      'coarse_raws'  the same rendered with focal / focal_length (if focal_length is given: the coarse field of view
+                     of the coarse-to-fine architectures), 'rgbs', 'depths', 'disps' (+ 'coarse_*').
+    NaN depths / disparities (rays that hit nothing) become 1 for the depth input types, as in the reference.  One
+    quirk is kept: for input_type 'rendered_depth' the coarse tensor is built from the FINE depths
+    (model_3detr.py:702)."""
+    poses = poses.reshape(-1, 3, 5)
+    H, W, focal = [float(v) for v in poses[0, :3, -1].cpu()]
+    H, W = int(H), int(W)
+    render_poses = poses[:, :3, :4]
+    out = {}
+
+    def one(f, tag):
+        K = np.array([[f, 0, 0.5 * W], [0, f, 0.5 * H], [0, 0, 1]])
+        rgbs, disps, raws, depths = render_path_device(render_poses, [H, W, focal], K, render_kwargs)
+        if input_type in _DEPTH_TYPES:
+            depths, disps = torch.nan_to_num(depths, nan=1.), torch.nan_to_num(disps, nan=1.)
+        out[tag + 'rgbs'], out[tag + 'disps'], out[tag + 'depths'] = rgbs, disps, depths
+        return rgbs, depths, raws
+
+    rgbs, depths, raws = one(focal, '')
+    out['raws'] = _assemble(input_type, rgbs, depths, raws, depths)
+    if focal_length is not None:
+        c_rgbs, c_depths, c_raws = one(focal / focal_length, 'coarse_')
+        out['coarse_raws'] = _assemble(input_type, c_rgbs, c_depths, c_raws, depths)
+    return out

@@ -575,3 +575,47 @@ def test_full_size_view_properties(dev):
     pick = rs.choice(640000, 96, replace=False)
     o = orc.render_rays(N(rays[pick]), sc, 64, 0, white_bkgd=True)
     assert maxabs(N(whole["rgb0"][pick]), o["rgb_map"]) < 1e-4 and maxabs(N(whole["acc0"][pick]), o["acc_map"]) < 1e-4
+
+
+@pytest.mark.parametrize("input_type", ["nerf", "rendered_rgb", "rendered_depth", "nerf_rendered_rgb_rendered_depth",
+                                        "rendered_rgb_rendered_depth"])
+def test_detector_inputs_assembly(dev, input_type):
+    """nerf_utils.detector_inputs against the reference's numpy assembly (model_3detr.py:619-712) applied to
+    render_path's outputs."""
+    import types
+    from nerf_loc_amd import nerf_utils
+    args = types.SimpleNamespace(nerf_render_rgb=True, nerf_render_depth=True)
+    _, kw, _ = nerf_utils.create_nerf_model(args, ckpt_path=None, device=dev, near=0.1, far=9.0)
+    kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(33, "B").items()})
+    kw["network_fn"].requires_grad_(False)
+    H, W, focal = 12, 9, 11.0
+    poses = np.zeros((2, 3, 5), F32)
+    for i in range(2):
+        poses[i, :, :4] = synth.pose_spherical(50.0 * i, -20.0, 1.5)[:3, :4]
+        poses[i, :, 4] = (H, W, focal)
+    got = nerf_utils.detector_inputs(T(poses, dev), kw, input_type=input_type, focal_length=1.2)
+
+    def ref_side(f):
+        K = np.array([[f, 0, 0.5 * W], [0, f, 0.5 * H], [0, 0, 1]])
+        rgbs, disps_vis, raws, disps = nerf_utils.render_path(T(poses[:, :, :4], dev), [H, W, focal], K, 1024 * 32, kw)
+        if input_type in ("rendered_depth", "nerf_rendered_depth", "nerf_rendered_rgb_rendered_depth", "rendered_rgb_rendered_depth"):
+            disps = np.nan_to_num(disps, nan=1.)
+        return rgbs, raws, disps
+
+    def assemble(rgbs, raws, disps, plain):
+        if input_type == "rendered_rgb":
+            return rgbs
+        if input_type == "rendered_depth":
+            return plain[..., None]
+        if input_type == "nerf_rendered_rgb_rendered_depth":
+            return np.concatenate((raws, np.repeat(rgbs[..., None], 4, axis=-1), np.repeat(disps[..., None, None], 4, axis=-1)), axis=-2)
+        if input_type == "rendered_rgb_rendered_depth":
+            return np.concatenate((np.repeat(rgbs[..., None], 4, axis=-1), np.repeat(disps[..., None, None], 4, axis=-1)), axis=-2)
+        return raws
+
+    rgbs, raws, disps = ref_side(focal)
+    c_rgbs, c_raws, c_disps = ref_side(focal / 1.2)
+    want, c_want = assemble(rgbs, raws, disps, disps), assemble(c_rgbs, c_raws, c_disps, disps)
+    assert got["raws"].is_cuda and np.array_equal(N(got["raws"]), want)
+    assert np.array_equal(N(got["coarse_raws"]), c_want)
+    assert not np.isnan(N(got["raws"])).any() or input_type in ("nerf", "rendered_rgb")
