@@ -155,20 +155,37 @@ __device__ __forceinline__ void sincos_any(float x, float& s, float& c) {
     }
 }
 
-template <bool FAST>
-__device__ __forceinline__ void encode_point(float px, float py, float pz, int h, float (&v)[32]) {
-    const float sc = h ? 32.0f : 1.0f;   // upper lane half: frequencies 2^5 .. 2^9
-    const float p[3] = {px * sc, py * sc, pz * sc};
+// FAST (bf16 mode): only the lowest frequency of each lane half goes through the transcendental unit; the higher
+// octaves follow from the double-angle identities (3 multiply-adds instead of 2 quarter-rate ops).  The error doubles
+// per octave: 4 octaves on top of ~1e-6 stay 100x below the bf16 rounding of the result.
+template <bool FAST, int NF>
+__device__ __forceinline__ void encode_octaves(const float (&p)[3], float* v) {
 #pragma unroll
-    for (int fl = 0; fl < 5; ++fl) {
+    for (int c3 = 0; c3 < 3; ++c3) {
+        float s, c;
+        sincos_any<FAST>(p[c3], s, c);
+        v[c3 * 2 + 0] = s;
+        v[c3 * 2 + 1] = c;
 #pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
-            float s, c;
-            sincos_any<FAST>(p[c3] * (float)(1 << fl), s, c);   // exact: power-of-two scaling
+        for (int fl = 1; fl < NF; ++fl) {
+            if (FAST) {
+                const float s2 = 2.0f * s * c;
+                c = __builtin_fmaf(-2.0f * s, s, 1.0f);
+                s = s2;
+            } else {
+                sincos_any<false>(p[c3] * (float)(1 << fl), s, c);   // exact: power-of-two scaling
+            }
             v[(fl * 3 + c3) * 2 + 0] = s;
             v[(fl * 3 + c3) * 2 + 1] = c;
         }
     }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void encode_point(float px, float py, float pz, int h, float (&v)[32]) {
+    const float sc = h ? 32.0f : 1.0f;   // upper lane half: frequencies 2^5 .. 2^9
+    const float p[3] = {px * sc, py * sc, pz * sc};
+    encode_octaves<FAST, 5>(p, &v[0]);
     v[30] = h ? pz : px;
     v[31] = h ? 0.0f : py;
 }
@@ -177,16 +194,7 @@ template <bool FAST>
 __device__ __forceinline__ void encode_view(float dx, float dy, float dz, int h, float (&v)[16]) {
     const float sc = h ? 4.0f : 1.0f;    // upper lane half: frequencies 2^2, 2^3
     const float p[3] = {dx * sc, dy * sc, dz * sc};
-#pragma unroll
-    for (int fl = 0; fl < 2; ++fl) {
-#pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
-            float s, c;
-            sincos_any<FAST>(p[c3] * (float)(1 << fl), s, c);
-            v[(fl * 3 + c3) * 2 + 0] = s;
-            v[(fl * 3 + c3) * 2 + 1] = c;
-        }
-    }
+    encode_octaves<FAST, 2>(p, &v[0]);
     v[12] = h ? 0.0f : dx;
     v[13] = h ? 0.0f : dy;
     v[14] = h ? 0.0f : dz;
