@@ -190,8 +190,8 @@ def main():
             kwargs[k].requires_grad_(True)
         rk = {k: v for k, v in kwargs.items() if k not in ("near", "far", "use_viewdirs", "ndc")}
         rk["perturb"] = 1.0
-        opt = torch.optim.Adam(list(kwargs["network_fn"].parameters()) + list(kwargs["network_fine"].parameters()),
-                               lr=5e-4, betas=(0.9, 0.999))
+        opt = train.FusedAdam(list(kwargs["network_fn"].parameters()) + list(kwargs["network_fine"].parameters()),
+                              lr=5e-4, betas=(0.9, 0.999))
         rays_all = torch.from_numpy(synth.random_rays(total, seed=0)).to(device)
         tgt_all = torch.rand(total, 3, generator=torch.Generator().manual_seed(0)).to(device)
         lo, hi, _ = ndist.shard_bounds(total, rank, world)

@@ -163,6 +163,16 @@ int nerf_mlp_backward(const void* packed_bwd, const float* d_raw, long long M, c
                       float* grad_tape, float* workspace, size_t workspace_bytes,
                       float* const* grads_host, void* stream);
 
+/* One Adam update of up to 64 parameter tensors in a single launch: torch.optim.Adam as the
+ * reference constructs it (run_nerf.py:225, betas (0.9, 0.999), eps 1e-8, no amsgrad), the
+ * optimizer.step() of run_nerf.py:787.  The four HOST arrays hold device pointers per tensor
+ * (parameter, gradient, exp_avg, exp_avg_sq), numel_host their element counts; step counts
+ * from 1.  Parameters and both moment buffers are updated in place.                          */
+int nerf_adam_step(int n_tensors, float* const* params_host, const float* const* grads_host,
+                   float* const* exp_avg_host, float* const* exp_avg_sq_host,
+                   const long long* numel_host, long long step, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@
 //
 // Bounds: forward and input gradients MFMA (1.19 and 1.11 MFLOP/sample); weight gradients MFMA with
 // 2 KB/sample/layer of tape traffic (HBM-balanced at float32).
+#include <math.h>
 #include "mlp_device.h"
 
 namespace nerf {
@@ -437,9 +438,76 @@ static int launch_wgrad_small(const float* d_raw, int c0, int N, const float* X,
     return NERF_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Adam (run_nerf.py:225: torch.optim.Adam(lr, betas=(0.9, 0.999))), all parameter tensors in one launch
+// ------------------------------------------------------------------------------------------
+constexpr int ADAM_MAX_TENSORS = 64;
+struct AdamArgs {
+    float* p[ADAM_MAX_TENSORS];
+    const float* g[ADAM_MAX_TENSORS];
+    float* m[ADAM_MAX_TENSORS];
+    float* v[ADAM_MAX_TENSORS];
+    long long end[ADAM_MAX_TENSORS];      // exclusive prefix ends of the element counts
+    int n_tensors;
+    float lr, beta1, beta2, eps, weight_decay;
+    float bias1, bias2_sqrt;              // 1 - beta1^t, sqrt(1 - beta2^t)
+};
+
+// torch.optim.Adam's single-tensor formula, operation by operation:
+//   g += wd * p;  m = m + (1 - b1) (g - m)  [lerp];  v = b2 v + (1 - b2) g g;
+//   p -= (lr / bias1) * m / (sqrt(v) / sqrt(bias2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    const long long total = a.end[a.n_tensors - 1];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int t = 0;
+        while (i >= a.end[t]) ++t;
+        const long long j = i - (t ? a.end[t - 1] : 0);
+        float g = a.g[t][j];
+        const float p = a.p[t][j];
+        if (a.weight_decay != 0.0f) g = fadd(g, fmul(a.weight_decay, p));
+        const float m0 = a.m[t][j], v0 = a.v[t][j];
+        const float m = fadd(m0, fmul(fsub(1.0f, a.beta1), fsub(g, m0)));
+        const float v = fadd(fmul(a.beta2, v0), fmul(fmul(fsub(1.0f, a.beta2), g), g));
+        const float denom = fadd(fdiv(sqrtf(v), a.bias2_sqrt), a.eps);
+        a.m[t][j] = m;
+        a.v[t][j] = v;
+        a.p[t][j] = fsub(p, fmul(fdiv(a.lr, a.bias1), fdiv(m, denom)));
+    }
+}
+
 }  // namespace nerf
 
 using namespace nerf;
+
+extern "C" int nerf_adam_step(int n_tensors, float* const* params_host, const float* const* grads_host,
+                              float* const* exp_avg_host, float* const* exp_avg_sq_host, const long long* numel_host,
+                              long long step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              void* stream) {
+    NERF_REQUIRE(n_tensors >= 1 && n_tensors <= ADAM_MAX_TENSORS, "nerf_adam_step: 1..%d tensors per call, got %d",
+                 ADAM_MAX_TENSORS, n_tensors);
+    NERF_REQUIRE(params_host && grads_host && exp_avg_host && exp_avg_sq_host && numel_host, "nerf_adam_step: null pointer");
+    NERF_REQUIRE(step >= 1, "nerf_adam_step: step counts from 1, got %lld", step);
+    AdamArgs a;
+    long long end = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        NERF_REQUIRE(numel_host[i] >= 0, "nerf_adam_step: negative size");
+        NERF_REQUIRE(numel_host[i] == 0 || (params_host[i] && grads_host[i] && exp_avg_host[i] && exp_avg_sq_host[i]),
+                     "nerf_adam_step: tensor %d has a null buffer", i);
+        a.p[i] = params_host[i]; a.g[i] = grads_host[i]; a.m[i] = exp_avg_host[i]; a.v[i] = exp_avg_sq_host[i];
+        end += numel_host[i];
+        a.end[i] = end;
+    }
+    if (end == 0) return NERF_OK;
+    a.n_tensors = n_tensors;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    long long blocks = (end + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+}
 
 extern "C" size_t nerf_train_tape_bytes(long long M) { return M < 0 ? 0 : (size_t)M * TAPE_FLOATS * sizeof(float); }
 extern "C" size_t nerf_train_grad_tape_bytes(long long M) { return M < 0 ? 0 : (size_t)M * GTAPE_FLOATS * sizeof(float); }

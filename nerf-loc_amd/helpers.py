@@ -152,7 +152,7 @@ class NeRF(nn.Module):
         else:
             order += ["output_linear.weight", "output_linear.bias"]
         tensors = [sd[k] for k in order]
-        key = (prec,) + tuple((t.data_ptr(), t._version) for t in tensors)
+        key = (prec, hip.WEIGHT_GENERATION[0]) + tuple((t.data_ptr(), t._version) for t in tensors)
         hit = self._pack_cache.get(prec)
         if hit is not None and hit[0] == key:
             return hit[1]

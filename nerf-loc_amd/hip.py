@@ -58,9 +58,18 @@ _SIGNATURES = {
     "nerf_mlp_backward": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, ctypes.c_longlong, _c_float_p, _c_float_p,
                                          _c_float_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
                                          ctypes.c_void_p]),
+    "nerf_adam_step": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.POINTER(ctypes.c_longlong), ctypes.c_longlong, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                      ctypes.c_void_p]),
 }
 
 _lib = None
+
+# Incremented whenever this library writes parameter tensors through raw pointers (adam_step): torch's own version
+# counters do not see those writes, and the packed-weight caches are keyed on this as well.
+WEIGHT_GENERATION = [0]
 
 
 class NerfHipError(RuntimeError):
@@ -351,3 +360,21 @@ def mlp_backward(packed_bwd, d_raw, tape, shapes):
         _check(lib().nerf_mlp_backward(ctypes.c_void_p(packed_bwd.data_ptr()), _ptr(d_raw), M, _ptr(tape), _ptr(gtape),
                                        _ptr(ws), ws.numel() * 4, arr, _stream(d_raw)), "nerf_mlp_backward")
     return grads
+
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay=0.0):
+    """In-place Adam update of up to 64 float32 tensors per launch (all on one device, contiguous)."""
+    n = len(params)
+    for i in range(0, n, 64):
+        sl = slice(i, min(n, i + 64))
+        ps, gs, ms, vs = params[sl], grads[sl], exp_avgs[sl], exp_avg_sqs[sl]
+        for t in ps + gs + ms + vs:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("adam_step needs contiguous float32 GPU tensors")
+        k = len(ps)
+        mk = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+        numel = (ctypes.c_longlong * k)(*[t.numel() for t in ps])
+        with torch.cuda.device(ps[0].device):
+            _check(lib().nerf_adam_step(k, mk(ps), mk(gs), mk(ms), mk(vs), numel, int(step), float(lr), float(beta1),
+                                        float(beta2), float(eps), float(weight_decay), _stream(ps[0])), "nerf_adam_step")
+    WEIGHT_GENERATION[0] += 1

@@ -305,7 +305,8 @@ def create_nerf(args, device=None):
                           skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
         grad_vars += list(model_fine.parameters())
     network_query_fn = NetworkQuery(embed_fn, embeddirs_fn, args.netchunk)
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    from .train import FusedAdam      # torch.optim.Adam's update and state layout, one launch per step
+    optimizer = FusedAdam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
 
     start = 0
     basedir, expname = args.basedir, args.expname

@@ -36,7 +36,7 @@ def _params(model):
 
 def _packed_backward(model, params):
     """Transposed-weight stream for the input-gradient chain, cached per weight version."""
-    key = tuple((p.data_ptr(), p._version) for p in params)
+    key = (hip.WEIGHT_GENERATION[0],) + tuple((p.data_ptr(), p._version) for p in params)
     hit = model._pack_cache.get("bwd")
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -177,6 +177,40 @@ def render_rays_autograd(rays, z_vals, network_fn, network_query_fn, N_samples, 
         ret['rgb0'], ret['disp0'], ret['acc0'] = ret0
         ret['z_std'] = z_std
     return ret
+
+
+# ---------------------------------------------------------------------------- optimizer (run_nerf.py:225, 787)
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam as the reference uses it (no amsgrad, no maximize), one kernel launch per step for all
+    parameter tensors.  param_groups and state_dict() have torch.optim.Adam's layout ('step', 'exp_avg',
+    'exp_avg_sq'), so the reference's learning-rate update loop and its checkpoints work unchanged."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps = [p for p in group['params'] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = torch.tensor(0.0)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['step'] += 1
+            step = int(self.state[ps[0]]['step'])
+            b1, b2 = group['betas']
+            hip.adam_step([p.data for p in ps], [p.grad.contiguous() for p in ps],
+                          [self.state[p]['exp_avg'] for p in ps], [self.state[p]['exp_avg_sq'] for p in ps],
+                          step, group['lr'], b1, b2, group['eps'], group['weight_decay'])
+        return loss
 
 
 # ---------------------------------------------------------------------------- the step itself (run_nerf.py:770-796)

@@ -210,7 +210,7 @@ def test_optimisation_reduces_the_loss(dev):
     rs = np.random.RandomState(4)
     target = T(rs.uniform(0, 1, size=(512, 3)).astype(F32), dev)
     nc, nf = load_net(synth.make_state_dict(7, "A"), dev), load_net(synth.make_state_dict(8, "A"), dev)
-    opt = torch.optim.Adam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    opt = train.FusedAdam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4, betas=(0.9, 0.999))
     kw = dict(network_query_fn=_query(dev), perturb=1.0, N_importance=128, network_fine=nf, N_samples=64, network_fn=nc,
               white_bkgd=True, raw_noise_std=0.0)
     losses = []
@@ -218,7 +218,7 @@ def test_optimisation_reduces_the_loss(dev):
         loss, psnr = train.train_step(rays, target, kw, opt, step + 1, 5e-4, 250)
         losses.append(float(loss))
     print("losses:", " ".join("%.4f" % l for l in losses))
-    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0]     # 0.1827 -> 0.1538 with torch.optim.Adam
     assert abs(opt.param_groups[0]["lr"] - 5e-4 * 0.1 ** (12 / 250000.0)) < 1e-12
 
 
@@ -250,3 +250,35 @@ def test_ray_bank_single_image_mode(dev):
         assert tuple(b.shape) == (2, 24, 3)
         assert np.abs(N(b[0]) - o[sel[:, 0], sel[:, 1]]).max() < 1e-6 and np.abs(N(b[1]) - d[sel[:, 0], sel[:, 1]]).max() < 1e-6
         assert np.array_equal(N(t), images[img_i][sel[:, 0], sel[:, 1]])
+
+
+def test_fused_adam_matches_torch_adam(dev):
+    """train.FusedAdam against torch.optim.Adam: same parameters after several steps with changing gradients and a
+    changing learning rate, and interchangeable state_dicts (the checkpoint format of run_nerf.py:803-811)."""
+    from nerf_loc_amd import train
+    torch.manual_seed(0)
+    shapes = [(256, 63), (256,), (1, 256), (3,), (128, 283)]
+    pa = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = train.FusedAdam(pa, lr=5e-4, betas=(0.9, 0.999))
+    ob = torch.optim.Adam(pb, lr=5e-4, betas=(0.9, 0.999))
+    for it in range(1, 8):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * (0.1 if it % 2 else 10.0)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+        lr = 5e-4 * 0.1 ** (it / 3.0)
+        for grp in oa.param_groups + ob.param_groups:
+            grp["lr"] = lr
+    for a, b in zip(pa, pb):
+        assert float((a - b).detach().abs().max()) <= 2e-7 * float(b.detach().abs().max())
+    # state dict round trip into a torch optimizer and back
+    oc = torch.optim.Adam([p.detach().clone().requires_grad_(True) for p in pa], lr=1.0)
+    oc.load_state_dict(oa.state_dict())
+    assert oc.param_groups[0]["lr"] == oa.param_groups[0]["lr"]
+    assert float(oc.state[oc.param_groups[0]["params"][0]]["step"]) == 7
+    od = train.FusedAdam([p.detach().clone().requires_grad_(True) for p in pa], lr=1.0)
+    od.load_state_dict(ob.state_dict())
+    k0 = od.param_groups[0]["params"][0]
+    assert torch.allclose(od.state[k0]["exp_avg"], ob.state[pb[0]]["exp_avg"])

@@ -32,7 +32,7 @@ def main():
     q = render.NetworkQuery(helpers.get_embedder(10, 0)[0], helpers.get_embedder(4, 0)[0], 1024 * 64)
     kw = dict(network_query_fn=q, perturb=1.0, N_importance=128, network_fine=nf, N_samples=64, network_fn=nc,
               white_bkgd=True, raw_noise_std=0.0)
-    opt = torch.optim.Adam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    opt = train.FusedAdam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4, betas=(0.9, 0.999))
     rays = torch.from_numpy(synth.random_rays(args.rays, seed=0)).to(dev)
     target = torch.rand(args.rays, 3, device=dev)
     for i in range(args.warmup):
