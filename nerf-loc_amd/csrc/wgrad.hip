@@ -1,0 +1,210 @@
+// Weight gradients of the NeRF network: dW[out, in] = sum_m G[m, out] X[m, in] with the sample index as the MFMA k
+// dimension (what autograd computes for the Linear layers of run_nerf_helpers.py:67-119 in loss.backward(),
+// run_nerf.py:785).  Kept in its own translation unit: the 256 accumulator registers of a wave live in AGPRs here,
+// whereas the layer-chain kernels are compiled with accumulators in arch VGPRs.
+#include "wgrad.h"
+#include "mlp_layout.h"
+#include "mlp_device.h"
+
+namespace nerf {
+
+// ------------------------------------------------------------------------------------------
+// weight gradients
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* G; int ldg; int N;      // gradient rows   [M, ldg], N <= 256 output features used
+    const float* X; int ldx; int K;      // layer inputs    [M, ldx], K <= 32 CT input features used
+    long long M;
+    long long chunk;                     // samples per workgroup (even)
+    float* part;                         // [grid][256][32 CT]
+    float* bpart;                        // [grid][256] column sums of G, or nullptr
+};
+
+// v_mfma_f32_32x32x2_f32 with i = output feature, j = input feature, k = sample: lane (r, h) feeds
+// G[m + h][32 rt + r] and X[m + h][32 ct + r].  Wave w owns output rows 64 w .. 64 w + 63 (N is a multiple of 64).
+template <int CT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void wgrad_kernel(WgradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = 64 * wave;
+    float* part = a.part + (size_t)blockIdx.x * 256 * (32 * CT);
+    if (row0 >= a.N) return;                       // whole wave: these rows are never read back
+    const long long m0 = (long long)blockIdx.x * a.chunk;
+    const long long m1 = m0 + a.chunk < a.M ? m0 + a.chunk : a.M;
+
+    f32x16 acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][ct][e] = 0.0f;
+    float bs0 = 0.0f, bs1 = 0.0f;
+
+    // N is a multiple of 64 and K = 32 CT (checked by the host), so only the sample index needs a bound.  Loads
+    // are unconditional from a clamped row and zeroed by a select: no branches in the loop.
+    constexpr int DEPTH = 4;                       // k-steps of operands in flight
+    float ga[DEPTH][2], xb[DEPTH][CT];
+    bool live[DEPTH];                              // sample of the slot inside [m0, m1); applied when consumed
+    const float* Gp = a.G + row0 + r;
+    const float* Xp = a.X + r;
+    const long long last = m1 - 1;
+    auto load = [&](int slot, long long m) {
+        const long long mm = m + h;
+        const bool ok = mm < m1;
+        const long long mc = ok ? mm : last;
+        const float* gp = Gp + (size_t)mc * a.ldg;
+        const float* xp = Xp + (size_t)mc * a.ldx;
+        ga[slot][0] = gp[0];
+        ga[slot][1] = gp[32];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) xb[slot][ct] = xp[32 * ct];
+        live[slot] = ok;
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) load(d, m0 + 2 * d);
+    for (long long mb = m0; mb < m1; mb += 2 * DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const long long m = mb + 2 * d;
+            // the loads of k-step d + 3 go out before the MFMAs of k-step d: keep the compiler from sinking them
+            __builtin_amdgcn_sched_barrier(0);
+            load((d + DEPTH - 1) % DEPTH, m + 2 * (DEPTH - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            // beyond the range only G is zeroed: X then comes from the clamped (real, finite) row and meets a zero
+            const float g0 = live[d] ? ga[d][0] : 0.0f, g1 = live[d] ? ga[d][1] : 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, xb[d][ct], acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, xb[d][ct], acc[1][ct], 0, 0, 0);
+            }
+            bs0 += g0; bs1 += g1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                part[(size_t)row * (32 * CT) + 32 * ct + r] = acc[i][ct][e];
+            }
+    }
+    if (a.bpart) {
+        bs0 += __shfl_xor(bs0, 32, WAVE);
+        bs1 += __shfl_xor(bs1, 32, WAVE);
+        if (h == 0) {
+            a.bpart[(size_t)blockIdx.x * 256 + row0 + r] = bs0;
+            a.bpart[(size_t)blockIdx.x * 256 + row0 + 32 + r] = bs1;
+        }
+    }
+}
+
+// Heads with 1 or 3 outputs (alpha_linear, rgb_linear): G is a column range of d_raw [M,4].  One thread
+// per input feature, samples of the block's range in sequence; X rows are read coalesced, G by broadcast.
+struct WsmallArgs {
+    const float* d_raw; int c0, N;       // output o <-> d_raw column c0 + o, N <= 3
+    const float* X; int K;               // [M, K], K = blockDim.x
+    long long M, chunk;
+    float* part;                         // [grid][4][K]
+    float* bpart;                        // [grid][4]
+};
+__global__ void wgrad_small_kernel(WsmallArgs a) {
+    const int k = threadIdx.x;
+    const long long m0 = (long long)blockIdx.x * a.chunk;
+    const long long m1 = m0 + a.chunk < a.M ? m0 + a.chunk : a.M;
+    float s[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
+    for (long long m = m0; m < m1; ++m) {
+        const float x = a.X[(size_t)m * a.K + k];
+        const float4 g = *reinterpret_cast<const float4*>(a.d_raw + (size_t)m * 4);
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+            if (o < a.N) { s[o] = fmaf(gv[a.c0 + o], x, s[o]); b[o] += gv[a.c0 + o]; }
+    }
+    for (int o = 0; o < a.N; ++o) a.part[((size_t)blockIdx.x * 4 + o) * a.K + k] = s[o];
+    if (k == 0) for (int o = 0; o < a.N; ++o) a.bpart[(size_t)blockIdx.x * 4 + o] = b[o];
+}
+
+// dst[row * ld + col_off + map(col)] = sum over parts, in part order.  map: 0 identity, 1 encoded-point
+// k-slot -> reference column, 2 encoded-view k-slot -> reference column (slots without a feature are dropped).
+struct ReduceArgs {
+    const float* part; int n_parts; int prow; int pcol;   // [n_parts][prow][pcol]
+    int N, K;                                             // rows / columns to emit
+    float* dst; int ld; int col_off; int map;
+};
+__global__ void wgrad_reduce_kernel(ReduceArgs a) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (col >= a.K || row >= a.N) return;
+    int dc = col;
+    if (a.map == 1) dc = pe_slot_feature(col >> 5, col & 31);
+    else if (a.map == 2) dc = view_slot_feature(col >> 4, col & 15);
+    if (dc < 0) return;
+    const float* p = a.part + (size_t)row * a.pcol + col;
+    const size_t stride = (size_t)a.prow * a.pcol;
+    // eight interleaved chains keep eight loads in flight; the order of additions is fixed
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 8 <= a.n_parts; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += p[(size_t)(i + j) * stride];
+    }
+    for (int j = 0; i < a.n_parts; ++i, ++j) s[j] += p[(size_t)i * stride];
+    a.dst[(size_t)row * a.ld + a.col_off + dc] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K, long long M,
+                        float* ws, float* dW, int ld, int col_off, int map, float* db, hipStream_t st) {
+    const int ct = (K + 31) / 32;
+    NERF_REQUIRE(N % 64 == 0 && N <= 256 && (K == 32 || K == 64 || K == 128 || K == 256),
+                 "weight gradient: unsupported shape %d x %d", N, K);
+    long long parts = (M + 511) / 512;             // at least 512 samples per workgroup
+    if (parts > WG_MAX_PARTS) parts = WG_MAX_PARTS;
+    if (parts > cu_count()) parts = cu_count();
+    if (parts < 1) parts = 1;
+    long long chunk = (M + parts - 1) / parts;
+    chunk += chunk & 1;
+    parts = (M + chunk - 1) / chunk;
+    WgradArgs a{G, ldg, N, X, ldx, K, M, chunk, ws, db ? ws + (size_t)WG_MAX_PARTS * 256 * 256 : nullptr};
+    const int ctp = ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : 8;
+    dim3 grid((unsigned)parts), block(256);
+    switch (ctp) {
+        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(wgrad_kernel<8>, grid, block, 0, st, a); break;
+    }
+    NERF_LAUNCH_CHECK();
+    ReduceArgs r{ws, (int)parts, 256, 32 * ctp, N, map == 0 ? K : 32 * ct, dW, ld, col_off, map};
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r.K + 63) / 64, N), dim3(64), 0, st, r);
+    NERF_LAUNCH_CHECK();
+    if (db) {
+        ReduceArgs rb{a.bpart, (int)parts, 1, 256, 1, N, db, N, 0, 0};
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N + 63) / 64, 1), dim3(64), 0, st, rb);
+        NERF_LAUNCH_CHECK();
+    }
+    return NERF_OK;
+}
+
+int launch_wgrad_small(const float* d_raw, int c0, int N, const float* X, int K, long long M, float* ws,
+                              float* dW, float* db, hipStream_t st) {
+    long long parts = (M + 255) / 256;
+    if (parts > 1024) parts = 1024;
+    const long long chunk = (M + parts - 1) / parts;
+    parts = (M + chunk - 1) / chunk;
+    WsmallArgs a{d_raw, c0, N, X, K, M, chunk, ws, ws + (size_t)1024 * 4 * 256};
+    hipLaunchKernelGGL(wgrad_small_kernel, dim3((unsigned)parts), dim3(K), 0, st, a);
+    NERF_LAUNCH_CHECK();
+    ReduceArgs r{ws, (int)parts, 4, K, N, K, dW, K, 0, 0};
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K + 63) / 64, N), dim3(64), 0, st, r);
+    NERF_LAUNCH_CHECK();
+    ReduceArgs rb{a.bpart, (int)parts, 1, 4, 1, N, db, N, 0, 0};
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1, 1), dim3(64), 0, st, rb);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+}
+
+
+}  // namespace nerf
