@@ -90,7 +90,11 @@ int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs, int output
                   int precision, void* packed_out, void* stream);
 
 /* raw_out [M, output_ch] with M = R*S (NERF_IN_FEATURES: M = R, S = 1).  With use_viewdirs
- * the output is [rgb(3), sigma] (run_nerf_helpers.py:115).                                 */
+ * the output is [rgb(3), sigma] (run_nerf_helpers.py:115).
+ * Domain of NERF_PREC_BF16: network inputs (features, coordinates) of magnitude <= 2^24 (the
+ * pack-time activation scales are derived from that bound; beyond it hidden activations may
+ * saturate), and the sin/cos features keep bf16 accuracy for |coordinate| up to about 100
+ * (fast range reduction).  NERF_PREC_F32 has neither limit.                                 */
 int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int output_ch,
                      int input_mode, const float* in0, const float* in1,
                      int R, int S, int ray_cols, float* raw_out, void* stream);
