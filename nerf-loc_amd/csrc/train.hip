@@ -35,7 +35,12 @@ struct GTapePtrs {
     float* dz[8]; float* dfeat; float* dzv;
 };
 
+// Rows are allocated for whole 128-sample workgroup tiles so that the kernels store without bounds checks; rows
+// beyond M hold values of clamped (repeated) inputs and are never read by the weight-gradient kernels.
+static long long pad128(long long M) { return (M + 127) / 128 * 128; }
+
 static TapePtrs tape_ptrs(float* base, long long M) {
+    M = pad128(M);
     TapePtrs t;
     size_t o = 0;
     t.pe = base + o; o += (size_t)M * TAPE_PE;
@@ -46,6 +51,7 @@ static TapePtrs tape_ptrs(float* base, long long M) {
     return t;
 }
 static GTapePtrs gtape_ptrs(float* base, long long M) {
+    M = pad128(M);
     GTapePtrs t;
     size_t o = 0;
     for (int i = 0; i < 8; ++i) { t.dz[i] = base + o; o += (size_t)M * 256; }
@@ -58,9 +64,8 @@ static GTapePtrs gtape_ptrs(float* base, long long M) {
 // Accumulator register 4 g + k of tile t holds feature 32 t + 8 g + 4 h + k of the lane's sample: four
 // 16-byte pieces per tile and lane in a sample-major row.
 struct SaveTile {
-    float* row;      // dst + m * ld + 4 h  (nullptr: sample beyond M, nothing is stored)
+    float* row;      // dst + m * ld + 4 h (the tapes are padded to whole 128-sample tiles: every lane stores)
     __device__ __forceinline__ void operator()(int t, float (&v)[16]) const {
-        if (!row) return;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(row + 32 * t + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
@@ -74,8 +79,8 @@ struct ActTile {
 };
 template <bool MASK>
 struct MaskSaveTile {
-    const float* act;   // forward activation row of a valid sample (+ 4 h)
-    float* row;         // destination row (+ 4 h) or nullptr
+    const float* act;   // forward activation row of the sample (+ 4 h)
+    float* row;         // destination row (+ 4 h)
     __device__ __forceinline__ ActTile fetch(int t) const {
         ActTile a;
         if (MASK) {
@@ -93,7 +98,7 @@ struct MaskSaveTile {
                 v[4 * g + 2] = a.q[g].z > 0.0f ? v[4 * g + 2] : 0.0f;
                 v[4 * g + 3] = a.q[g].w > 0.0f ? v[4 * g + 3] : 0.0f;
             }
-            if (row) *reinterpret_cast<float4*>(row + 32 * t + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            *reinterpret_cast<float4*>(row + 32 * t + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
         }
     }
 };
@@ -124,7 +129,7 @@ void mlp_f32_train_kernel(MlpArgs a, TapePtrs tp) {
             fetch_raw<true>(a, mc, cur);
             encode_raw<true, false>(cur, h, pe, vw);
         }
-        if (valid) {
+        {
             float4* q = reinterpret_cast<float4*>(tp.pe + (size_t)m * TAPE_PE + 32 * h);
 #pragma unroll
             for (int g = 0; g < 8; ++g) q[g] = make_float4(pe[4 * g], pe[4 * g + 1], pe[4 * g + 2], pe[4 * g + 3]);
@@ -132,7 +137,7 @@ void mlp_f32_train_kernel(MlpArgs a, TapePtrs tp) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) qv[g] = make_float4(vw[4 * g], vw[4 * g + 1], vw[4 * g + 2], vw[4 * g + 3]);
         }
-        auto save256 = [&](float* base) { return SaveTile{valid ? base + (size_t)m * 256 + 4 * h : nullptr}; };
+        auto save256 = [&](float* base) { return SaveTile{base + (size_t)m * 256 + 4 * h}; };
 
         float A[8][16], B[8][16];
         int pos = 0, bt = 0;
@@ -153,7 +158,7 @@ void mlp_f32_train_kernel(MlpArgs a, TapePtrs tp) {
             o3 = acc[3];
         }
         layer_f32<4, false, 8, true, true>(p, pos, bt, h, pe, A, vw, B,
-                                           SaveTile{valid ? tp.hv + (size_t)m * 128 + 4 * h : nullptr});
+                                           SaveTile{tp.hv + (size_t)m * 128 + 4 * h});
         f32x16 acc = bias_tile(p.lds, bt, h);
         mma_run_f32<16>(p, pos, acc, &B[0][0]);
         if (valid && h == 0) *reinterpret_cast<float4*>(a.out + (size_t)m * 4) = make_float4(acc[0], acc[1], acc[2], o3);
@@ -217,13 +222,13 @@ void mlp_dgrad_f32_kernel(DgradArgs a) {
         const float dsig[4] = {h ? 0.0f : dr.w, 0.0f, 0.0f, 0.0f};
         const float none[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         auto rows = [&](const float* act, float* dst, int ld) {
-            return MaskSaveTile<true>{act + (size_t)mc * ld + 4 * h, valid ? dst + (size_t)m * ld + 4 * h : nullptr};
+            return MaskSaveTile<true>{act + (size_t)m * ld + 4 * h, dst + (size_t)m * ld + 4 * h};
         };
         float A[8][16], B[8][16];
         int pos = 0;
         layer_bwd_f32<4, 1, false>(p, pos, &drgb[0], none, B, rows(a.tp.hv, a.gt.dzv, 128));
         layer_bwd_f32<8, 16, false>(p, pos, &B[0][0], none, A,
-                                    MaskSaveTile<false>{nullptr, valid ? a.gt.dfeat + (size_t)m * 256 + 4 * h : nullptr});
+                                    MaskSaveTile<false>{nullptr, a.gt.dfeat + (size_t)m * 256 + 4 * h});
         layer_bwd_f32<8, 32, true>(p, pos, &A[0][0], dsig, B, rows(a.tp.h[7], a.gt.dz[7], 256));
         layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[6], a.gt.dz[6], 256));   // pts_linears.7^T
         layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(a.tp.h[5], a.gt.dz[5], 256));   // .6
@@ -310,8 +315,8 @@ extern "C" int nerf_adam_step(int n_tensors, float* const* params_host, const fl
     return NERF_OK;
 }
 
-extern "C" size_t nerf_train_tape_bytes(long long M) { return M < 0 ? 0 : (size_t)M * TAPE_FLOATS * sizeof(float); }
-extern "C" size_t nerf_train_grad_tape_bytes(long long M) { return M < 0 ? 0 : (size_t)M * GTAPE_FLOATS * sizeof(float); }
+extern "C" size_t nerf_train_tape_bytes(long long M) { return M < 0 ? 0 : (size_t)pad128(M) * TAPE_FLOATS * sizeof(float); }
+extern "C" size_t nerf_train_grad_tape_bytes(long long M) { return M < 0 ? 0 : (size_t)pad128(M) * GTAPE_FLOATS * sizeof(float); }
 extern "C" size_t nerf_train_workspace_bytes(void) {
     return ((size_t)WG_MAX_PARTS * 256 * 256 + (size_t)WG_MAX_PARTS * 256) * sizeof(float);
 }
