@@ -130,11 +130,12 @@ inline NetDesc make_net_desc(bool use_viewdirs, int output_ch) {
     return n;
 }
 
-// Input-gradient chain of the view-dependent network, float32 only.  Layers in execution order:
+// Input-gradient chain, float32 only.  Layers in execution order, with view directions:
 //   rgb_linear^T (3 -> 128), views_linears.0^T restricted to the feature columns (128 -> 256),
 //   feature_linear^T plus alpha_linear^T (256 + 1 -> 256), then pts_linears 7..1 transposed
-//   (layer 5: only the 256 hidden columns, the encoded-input columns have no leaves behind them).
-inline NetDesc make_backward_desc() {
+//   (layer 5: only the 256 hidden columns, the encoded-input columns have no leaves behind them);
+// without: output_linear^T (output_ch -> 256), then pts_linears 7..1.
+inline NetDesc make_backward_desc(bool use_viewdirs, int output_ch) {
     NetDesc n{};
     int li = 0;
     auto add = [&](int tiles, int out_dim, int kfeats, int w_idx, int in_dim, int row_off, int k_limit) -> LayerDesc& {
@@ -145,17 +146,22 @@ inline NetDesc make_backward_desc() {
         n.layer[li] = L;
         return n.layer[li++];
     };
-    add(4, 128, 8, 22, 128, 0, 3);                 // d(view hidden) = rgb_linear.weight^T d(rgb)
-    add(8, 256, 128, 16, 283, 0, 128);             // d(feature) = views_linears.0.weight[:, :256]^T d(view hidden)
-    LayerDesc& fa = add(8, 256, 256, 18, 256, 0, 256);   // d(h8) = feature^T d(feature) + alpha^T d(sigma)
-    fa.extra_frags = 1; fa.w2_idx = 20; fa.in_dim2 = 256; fa.k_limit2 = 1;
+    if (use_viewdirs) {
+        add(4, 128, 8, 22, 128, 0, 3);                 // d(view hidden) = rgb_linear.weight^T d(rgb)
+        add(8, 256, 128, 16, 283, 0, 128);             // d(feature) = views_linears.0.weight[:, :256]^T d(view hidden)
+        LayerDesc& fa = add(8, 256, 256, 18, 256, 0, 256);   // d(h8) = feature^T d(feature) + alpha^T d(sigma)
+        fa.extra_frags = 1; fa.w2_idx = 20; fa.in_dim2 = 256; fa.k_limit2 = 1;
+    } else {
+        add(8, 256, 8, 18, 256, 0, output_ch);         // d(h8) = output_linear.weight^T d(raw)
+    }
     for (int i = 7; i >= 1; --i) add(8, 256, 256, 2 * i, i == 5 ? 319 : 256, i == 5 ? 63 : 0, 256);
     n.n_layers = li;
     n.n_bias_tiles = 0;
     return n;
 }
-constexpr int FRAGS_BWD_F32 = 4 * 1 + 8 * 16 + 8 * 33 + 7 * 8 * 32;                  // 2188
-constexpr int FRAGS_BWD_F32_PADDED = (FRAGS_BWD_F32 + STAGE_FRAGS - 1) / STAGE_FRAGS * STAGE_FRAGS;   // 2192
+constexpr int FRAGS_BWD_F32_VD = 4 * 1 + 8 * 16 + 8 * 33 + 7 * 8 * 32;               // 2188
+constexpr int FRAGS_BWD_F32_NOVD = 8 * 1 + 7 * 8 * 32;                                // 1800
+constexpr int pad_to_stage(int f) { return (f + STAGE_FRAGS - 1) / STAGE_FRAGS * STAGE_FRAGS; }
 
 inline int total_frags(const NetDesc& n, int prec_bf16) {
     int t = 0;

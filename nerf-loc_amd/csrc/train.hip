@@ -25,8 +25,8 @@
 namespace nerf {
 
 constexpr int TAPE_PE = 64, TAPE_VW = 32;
-constexpr int TAPE_FLOATS = TAPE_PE + TAPE_VW + 8 * 256 + 256 + 128;   // 2528 per sample
-constexpr int GTAPE_FLOATS = 8 * 256 + 256 + 128;                      // 2432 per sample
+constexpr int tape_floats(bool vd) { return vd ? TAPE_PE + TAPE_VW + 8 * 256 + 256 + 128 : TAPE_PE + 8 * 256; }   // per sample
+constexpr int gtape_floats(bool vd) { return vd ? 8 * 256 + 256 + 128 : 8 * 256; }
 
 struct TapePtrs {
     float* pe; float* vw; float* h[8]; float* feat; float* hv;
@@ -39,24 +39,28 @@ struct GTapePtrs {
 // beyond M hold values of clamped (repeated) inputs and are never read by the weight-gradient kernels.
 static long long pad128(long long M) { return (M + 127) / 128 * 128; }
 
-static TapePtrs tape_ptrs(float* base, long long M) {
+static TapePtrs tape_ptrs(float* base, long long M, bool vd) {
     M = pad128(M);
-    TapePtrs t;
+    TapePtrs t{};
     size_t o = 0;
     t.pe = base + o; o += (size_t)M * TAPE_PE;
-    t.vw = base + o; o += (size_t)M * TAPE_VW;
+    if (vd) { t.vw = base + o; o += (size_t)M * TAPE_VW; }
     for (int i = 0; i < 8; ++i) { t.h[i] = base + o; o += (size_t)M * 256; }
-    t.feat = base + o; o += (size_t)M * 256;
-    t.hv = base + o;
+    if (vd) {
+        t.feat = base + o; o += (size_t)M * 256;
+        t.hv = base + o;
+    }
     return t;
 }
-static GTapePtrs gtape_ptrs(float* base, long long M) {
+static GTapePtrs gtape_ptrs(float* base, long long M, bool vd) {
     M = pad128(M);
-    GTapePtrs t;
+    GTapePtrs t{};
     size_t o = 0;
     for (int i = 0; i < 8; ++i) { t.dz[i] = base + o; o += (size_t)M * 256; }
-    t.dfeat = base + o; o += (size_t)M * 256;
-    t.dzv = base + o;
+    if (vd) {
+        t.dfeat = base + o; o += (size_t)M * 256;
+        t.dzv = base + o;
+    }
     return t;
 }
 
@@ -106,6 +110,7 @@ struct MaskSaveTile {
 // ------------------------------------------------------------------------------------------
 // forward with tape
 // ------------------------------------------------------------------------------------------
+template <bool VD, int OUT_CH>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp_f32_train_kernel(MlpArgs a, TapePtrs tp) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
@@ -123,19 +128,21 @@ void mlp_f32_train_kernel(MlpArgs a, TapePtrs tp) {
         const unsigned mc = valid ? m : Mu - 1;
         float pe[32], vw[16];
         if (feat_mode) {
-            load_features<true>(a, mc, h, pe, vw);
+            load_features<VD>(a, mc, h, pe, vw);
         } else {
             RawIn cur;
-            fetch_raw<true>(a, mc, cur);
-            encode_raw<true, false>(cur, h, pe, vw);
+            fetch_raw<VD>(a, mc, cur);
+            encode_raw<VD, false>(cur, h, pe, vw);
         }
         {
             float4* q = reinterpret_cast<float4*>(tp.pe + (size_t)m * TAPE_PE + 32 * h);
 #pragma unroll
             for (int g = 0; g < 8; ++g) q[g] = make_float4(pe[4 * g], pe[4 * g + 1], pe[4 * g + 2], pe[4 * g + 3]);
-            float4* qv = reinterpret_cast<float4*>(tp.vw + (size_t)m * TAPE_VW + 16 * h);
+            if (VD) {
+                float4* qv = reinterpret_cast<float4*>(tp.vw + (size_t)m * TAPE_VW + 16 * h);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) qv[g] = make_float4(vw[4 * g], vw[4 * g + 1], vw[4 * g + 2], vw[4 * g + 3]);
+                for (int g = 0; g < 4; ++g) qv[g] = make_float4(vw[4 * g], vw[4 * g + 1], vw[4 * g + 2], vw[4 * g + 3]);
+            }
         }
         auto save256 = [&](float* base) { return SaveTile{base + (size_t)m * 256 + 4 * h}; };
 
@@ -149,19 +156,33 @@ void mlp_f32_train_kernel(MlpArgs a, TapePtrs tp) {
         layer_f32<8, true, 8, false, true>(p, pos, bt, h, pe, A, vw, B, save256(tp.h[5]));
         layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, B, vw, A, save256(tp.h[6]));
         layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, A, vw, B, save256(tp.h[7]));
-        layer_f32<8, false, 8, false, false>(p, pos, bt, h, pe, B, vw, A, save256(tp.feat));
-        float o3;
-        {
+        if (VD) {
+            layer_f32<8, false, 8, false, false>(p, pos, bt, h, pe, B, vw, A, save256(tp.feat));
+            float o3;
+            {
+                f32x16 acc = bias_tile(p.lds, bt, h);
+                mma_run_f32<32>(p, pos, acc, &B[0][0]);
+                pos += 32; bt += 1;
+                o3 = acc[3];
+            }
+            layer_f32<4, false, 8, true, true>(p, pos, bt, h, pe, A, vw, B, SaveTile{tp.hv + (size_t)m * 128 + 4 * h});
+            f32x16 acc = bias_tile(p.lds, bt, h);
+            mma_run_f32<16>(p, pos, acc, &B[0][0]);
+            if (valid && h == 0) *reinterpret_cast<float4*>(a.out + (size_t)m * 4) = make_float4(acc[0], acc[1], acc[2], o3);
+        } else {
             f32x16 acc = bias_tile(p.lds, bt, h);
             mma_run_f32<32>(p, pos, acc, &B[0][0]);
-            pos += 32; bt += 1;
-            o3 = acc[3];
+            if (valid) {
+                float* o = a.out + (size_t)m * OUT_CH;
+                if (OUT_CH == 4) {
+                    if (h == 0) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                } else if (h == 0) {
+                    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+                } else {
+                    o[4] = acc[0];       // row 4 of the tile lives in register 0 of the upper lane half
+                }
+            }
         }
-        layer_f32<4, false, 8, true, true>(p, pos, bt, h, pe, A, vw, B,
-                                           SaveTile{tp.hv + (size_t)m * 128 + 4 * h});
-        f32x16 acc = bias_tile(p.lds, bt, h);
-        mma_run_f32<16>(p, pos, acc, &B[0][0]);
-        if (valid && h == 0) *reinterpret_cast<float4*>(a.out + (size_t)m * 4) = make_float4(acc[0], acc[1], acc[2], o3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -198,6 +219,7 @@ __device__ __forceinline__ void layer_bwd_f32(Pipe& p, int& pos, const float* hi
     }
 }
 
+template <bool VD, int OUT_CH>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp_dgrad_f32_kernel(DgradArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
@@ -216,20 +238,29 @@ void mlp_dgrad_f32_kernel(DgradArgs a) {
         const unsigned m = (unsigned)tile * 128u + wave * 32 + c;
         const bool valid = m < Mu;
         const unsigned mc = valid ? m : Mu - 1;
-        const float4 dr = *reinterpret_cast<const float4*>(a.d_raw + (size_t)mc * 4);
         // k slot (j, h) of a one-fragment part is input index j + 4 h (mlp_layout.h, hidden convention, tile 0)
-        const float drgb[4] = {h ? 0.0f : dr.x, h ? 0.0f : dr.y, h ? 0.0f : dr.z, 0.0f};
-        const float dsig[4] = {h ? 0.0f : dr.w, 0.0f, 0.0f, 0.0f};
+        const float* drp = a.d_raw + (size_t)mc * OUT_CH;
+        float dr[5];
+#pragma unroll
+        for (int k = 0; k < OUT_CH; ++k) dr[k] = drp[k];
         const float none[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         auto rows = [&](const float* act, float* dst, int ld) {
             return MaskSaveTile<true>{act + (size_t)m * ld + 4 * h, dst + (size_t)m * ld + 4 * h};
         };
         float A[8][16], B[8][16];
         int pos = 0;
-        layer_bwd_f32<4, 1, false>(p, pos, &drgb[0], none, B, rows(a.tp.hv, a.gt.dzv, 128));
-        layer_bwd_f32<8, 16, false>(p, pos, &B[0][0], none, A,
-                                    MaskSaveTile<false>{nullptr, a.gt.dfeat + (size_t)m * 256 + 4 * h});
-        layer_bwd_f32<8, 32, true>(p, pos, &A[0][0], dsig, B, rows(a.tp.h[7], a.gt.dz[7], 256));
+        if (VD) {
+            const float drgb[4] = {h ? 0.0f : dr[0], h ? 0.0f : dr[1], h ? 0.0f : dr[2], 0.0f};
+            const float dsig[4] = {h ? 0.0f : dr[3], 0.0f, 0.0f, 0.0f};
+            layer_bwd_f32<4, 1, false>(p, pos, &drgb[0], none, B, rows(a.tp.hv, a.gt.dzv, 128));
+            layer_bwd_f32<8, 16, false>(p, pos, &B[0][0], none, A,
+                                        MaskSaveTile<false>{nullptr, a.gt.dfeat + (size_t)m * 256 + 4 * h});
+            layer_bwd_f32<8, 32, true>(p, pos, &A[0][0], dsig, B, rows(a.tp.h[7], a.gt.dz[7], 256));
+        } else {
+            const float dout[4] = {h ? (OUT_CH > 4 ? dr[OUT_CH > 4 ? 4 : 0] : 0.0f) : dr[0], h ? 0.0f : dr[1], h ? 0.0f : dr[2],
+                                   h ? 0.0f : dr[3]};
+            layer_bwd_f32<8, 1, false>(p, pos, &dout[0], none, B, rows(a.tp.h[7], a.gt.dz[7], 256));
+        }
         layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[6], a.gt.dz[6], 256));   // pts_linears.7^T
         layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(a.tp.h[5], a.gt.dz[5], 256));   // .6
         layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[4], a.gt.dz[4], 256));   // .5 (hidden columns)
@@ -239,7 +270,8 @@ void mlp_dgrad_f32_kernel(DgradArgs a) {
         layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[0], a.gt.dz[0], 256));   // .1
         // zero fragments that pad the stream to a whole stage
 #pragma unroll
-        for (int g = 0; g < FRAGS_BWD_F32_PADDED - FRAGS_BWD_F32; ++g) p.tick(pos + g);
+        for (int g = 0; g < pad_to_stage(VD ? FRAGS_BWD_F32_VD : FRAGS_BWD_F32_NOVD) - (VD ? FRAGS_BWD_F32_VD : FRAGS_BWD_F32_NOVD); ++g)
+            p.tick(pos + g);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -315,82 +347,113 @@ extern "C" int nerf_adam_step(int n_tensors, float* const* params_host, const fl
     return NERF_OK;
 }
 
-extern "C" size_t nerf_train_tape_bytes(long long M) { return M < 0 ? 0 : (size_t)pad128(M) * TAPE_FLOATS * sizeof(float); }
-extern "C" size_t nerf_train_grad_tape_bytes(long long M) { return M < 0 ? 0 : (size_t)pad128(M) * GTAPE_FLOATS * sizeof(float); }
+static int check_arch(const char* who, int use_viewdirs, int output_ch) {
+    if (use_viewdirs) NERF_REQUIRE(output_ch == 4, "%s: output_ch must be 4 with view directions", who);
+    else NERF_REQUIRE(output_ch == 4 || output_ch == 5, "%s: output_ch must be 4 or 5, got %d", who, output_ch);
+    return NERF_OK;
+}
+static int bwd_frags(int use_viewdirs) { return use_viewdirs ? FRAGS_BWD_F32_VD : FRAGS_BWD_F32_NOVD; }
+
+extern "C" size_t nerf_train_tape_bytes(long long M, int use_viewdirs) {
+    return M < 0 ? 0 : (size_t)pad128(M) * tape_floats(use_viewdirs != 0) * sizeof(float);
+}
+extern "C" size_t nerf_train_grad_tape_bytes(long long M, int use_viewdirs) {
+    return M < 0 ? 0 : (size_t)pad128(M) * gtape_floats(use_viewdirs != 0) * sizeof(float);
+}
 extern "C" size_t nerf_train_workspace_bytes(void) {
     return ((size_t)WG_MAX_PARTS * 256 * 256 + (size_t)WG_MAX_PARTS * 256) * sizeof(float);
 }
-extern "C" size_t nerf_mlp_backward_packed_bytes(void) { return (size_t)FRAGS_BWD_F32_PADDED * FRAG_BYTES; }
+extern "C" size_t nerf_mlp_backward_packed_bytes(int use_viewdirs) {
+    return (size_t)pad_to_stage(bwd_frags(use_viewdirs)) * FRAG_BYTES;
+}
 
-extern "C" int nerf_mlp_pack_backward(const float* const* tensors_host, void* packed_out, void* stream) {
+extern "C" int nerf_mlp_pack_backward(const float* const* tensors_host, int use_viewdirs, int output_ch,
+                                      void* packed_out, void* stream) {
     NERF_REQUIRE(tensors_host && packed_out, "nerf_mlp_pack_backward: null pointer");
+    if (int rc = check_arch("nerf_mlp_pack_backward", use_viewdirs, output_ch)) return rc;
     PackArgs a;
-    a.net = make_backward_desc();
+    a.net = make_backward_desc(use_viewdirs != 0, output_ch);
     a.bf16 = 0;
     a.total_frags = total_frags(a.net, 0);
-    a.padded_frags = FRAGS_BWD_F32_PADDED;
-    NERF_REQUIRE(a.total_frags == FRAGS_BWD_F32, "nerf_mlp_pack_backward: internal layout mismatch");
-    for (int i = 0; i < 24; ++i) {
-        a.t[i] = tensors_host[i];
-        if (i % 2 == 0) NERF_REQUIRE(a.t[i], "nerf_mlp_pack_backward: weight tensor %d is null", i);
+    a.padded_frags = pad_to_stage(bwd_frags(use_viewdirs));
+    NERF_REQUIRE(a.total_frags == bwd_frags(use_viewdirs), "nerf_mlp_pack_backward: internal layout mismatch");
+    const int n_t = use_viewdirs ? 24 : 20;
+    for (int i = 0; i < 24; ++i) a.t[i] = i < n_t ? tensors_host[i] : nullptr;
+    for (int i = 0; i < a.net.n_layers; ++i) {
+        NERF_REQUIRE(a.t[a.net.layer[i].w_idx], "nerf_mlp_pack_backward: weight tensor %d is null", a.net.layer[i].w_idx);
+        if (a.net.layer[i].extra_frags) NERF_REQUIRE(a.t[a.net.layer[i].w2_idx], "nerf_mlp_pack_backward: weight tensor %d is null", a.net.layer[i].w2_idx);
     }
     a.out = static_cast<unsigned char*>(packed_out);
     return launch_pack(a, as_stream(stream));
 }
 
-extern "C" int nerf_mlp_forward_train(const void* packed, int input_mode, const float* in0, const float* in1, int R,
-                                      int S, int ray_cols, float* raw_out, float* tape, void* stream) {
+extern "C" int nerf_mlp_forward_train(const void* packed, int use_viewdirs, int output_ch, int input_mode,
+                                      const float* in0, const float* in1, int R, int S, int ray_cols, float* raw_out,
+                                      float* tape, void* stream) {
     NERF_REQUIRE(packed && (R == 0 || (in0 && raw_out && tape)), "nerf_mlp_forward_train: null pointer");
     NERF_REQUIRE(R >= 0 && S >= 1, "nerf_mlp_forward_train: bad shape R=%d S=%d", R, S);
+    if (int rc = check_arch("nerf_mlp_forward_train", use_viewdirs, output_ch)) return rc;
     switch (input_mode) {
         case NERF_IN_FEATURES: NERF_REQUIRE(S == 1, "nerf_mlp_forward_train: feature input is flat (S = 1)"); break;
-        case NERF_IN_POINTS: NERF_REQUIRE(R == 0 || in1, "nerf_mlp_forward_train: view directions missing"); break;
+        case NERF_IN_POINTS: NERF_REQUIRE(R == 0 || !use_viewdirs || in1, "nerf_mlp_forward_train: view directions missing"); break;
         case NERF_IN_RAYS:
             NERF_REQUIRE(R == 0 || in1, "nerf_mlp_forward_train: z_vals missing");
-            NERF_REQUIRE(ray_cols >= 11, "nerf_mlp_forward_train: rays need 11 columns, got %d", ray_cols);
+            NERF_REQUIRE(ray_cols >= (use_viewdirs ? 11 : 8), "nerf_mlp_forward_train: rays need %d columns, got %d",
+                         use_viewdirs ? 11 : 8, ray_cols);
             break;
         default: NERF_REQUIRE(false, "nerf_mlp_forward_train: unknown input mode %d", input_mode);
     }
-    NERF_REQUIRE(((uintptr_t)raw_out & 15) == 0 && ((uintptr_t)tape & 15) == 0 && ((uintptr_t)packed & 15) == 0,
+    NERF_REQUIRE(((uintptr_t)tape & 15) == 0 && ((uintptr_t)packed & 15) == 0 && (output_ch != 4 || ((uintptr_t)raw_out & 15) == 0),
                  "nerf_mlp_forward_train: buffers must be 16-byte aligned");
     const long long M = (long long)R * S;
     if (M == 0) return NERF_OK;
     NERF_REQUIRE(M < (1ll << 31) - 512, "nerf_mlp_forward_train: at most 2^31 - 512 samples per launch, got %lld", M);
     MlpArgs a;
     a.packed = static_cast<const unsigned char*>(packed);
-    a.n_stages = FRAGS_F32_VD / STAGE_FRAGS;
-    a.n_bias_tiles = BIAS_TILES_VD;
+    a.n_stages = (use_viewdirs ? FRAGS_F32_VD : FRAGS_F32_NOVD) / STAGE_FRAGS;
+    a.n_bias_tiles = use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD;
     a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
     const long long n_tiles = (M + 127) / 128;
-    const int grid = (int)(n_tiles < cu_count() ? n_tiles : cu_count());
-    hipLaunchKernelGGL(mlp_f32_train_kernel, dim3(grid), dim3(MLP_THREADS), 0, as_stream(stream), a, tape_ptrs(tape, M));
+    const dim3 grid((unsigned)(n_tiles < cu_count() ? n_tiles : cu_count())), block(MLP_THREADS);
+    const TapePtrs tp = tape_ptrs(tape, M, use_viewdirs != 0);
+    hipStream_t st = as_stream(stream);
+    if (use_viewdirs) hipLaunchKernelGGL((mlp_f32_train_kernel<true, 4>), grid, block, 0, st, a, tp);
+    else if (output_ch == 4) hipLaunchKernelGGL((mlp_f32_train_kernel<false, 4>), grid, block, 0, st, a, tp);
+    else hipLaunchKernelGGL((mlp_f32_train_kernel<false, 5>), grid, block, 0, st, a, tp);
     NERF_LAUNCH_CHECK();
     return NERF_OK;
 }
 
-extern "C" int nerf_mlp_backward(const void* packed_bwd, const float* d_raw, long long M, const float* tape,
-                                 float* grad_tape, float* workspace, size_t workspace_bytes,
+extern "C" int nerf_mlp_backward(const void* packed_bwd, int use_viewdirs, int output_ch, const float* d_raw, long long M,
+                                 const float* tape, float* grad_tape, float* workspace, size_t workspace_bytes,
                                  float* const* grads_host, void* stream) {
     NERF_REQUIRE(packed_bwd && d_raw && tape && grad_tape && workspace && grads_host, "nerf_mlp_backward: null pointer");
+    if (int rc = check_arch("nerf_mlp_backward", use_viewdirs, output_ch)) return rc;
     NERF_REQUIRE(workspace_bytes >= nerf_train_workspace_bytes(), "nerf_mlp_backward: workspace of %zu bytes, %zu needed",
                  workspace_bytes, nerf_train_workspace_bytes());
     NERF_REQUIRE(((uintptr_t)d_raw & 15) == 0 && ((uintptr_t)tape & 15) == 0 && ((uintptr_t)grad_tape & 15) == 0,
                  "nerf_mlp_backward: buffers must be 16-byte aligned");
     NERF_REQUIRE(M >= 1 && M < (1ll << 31) - 512, "nerf_mlp_backward: bad sample count %lld", M);
-    for (int i = 0; i < 24; ++i) NERF_REQUIRE(grads_host[i], "nerf_mlp_backward: gradient tensor %d is null", i);
+    const int n_t = use_viewdirs ? 24 : 20;
+    for (int i = 0; i < n_t; ++i)
+        if (use_viewdirs || (i != 16 && i != 17)) NERF_REQUIRE(grads_host[i], "nerf_mlp_backward: gradient tensor %d is null", i);
     hipStream_t st = as_stream(stream);
-    const TapePtrs tp = tape_ptrs(const_cast<float*>(tape), M);
-    const GTapePtrs gt = gtape_ptrs(grad_tape, M);
+    const TapePtrs tp = tape_ptrs(const_cast<float*>(tape), M, use_viewdirs != 0);
+    const GTapePtrs gt = gtape_ptrs(grad_tape, M, use_viewdirs != 0);
     DgradArgs d;
     d.packed = static_cast<const unsigned char*>(packed_bwd);
-    d.n_stages = FRAGS_BWD_F32_PADDED / STAGE_FRAGS;
+    d.n_stages = pad_to_stage(bwd_frags(use_viewdirs)) / STAGE_FRAGS;
     d.M = M; d.d_raw = d_raw; d.tp = tp; d.gt = gt;
     const long long n_tiles = (M + 127) / 128;
-    const int grid = (int)(n_tiles < cu_count() ? n_tiles : cu_count());
-    hipLaunchKernelGGL(mlp_dgrad_f32_kernel, dim3(grid), dim3(MLP_THREADS), 0, st, d);
+    const dim3 grid((unsigned)(n_tiles < cu_count() ? n_tiles : cu_count())), block(MLP_THREADS);
+    if (use_viewdirs) hipLaunchKernelGGL((mlp_dgrad_f32_kernel<true, 4>), grid, block, 0, st, d);
+    else if (output_ch == 4) hipLaunchKernelGGL((mlp_dgrad_f32_kernel<false, 4>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((mlp_dgrad_f32_kernel<false, 5>), grid, block, 0, st, d);
     NERF_LAUNCH_CHECK();
 
-    float* const* g = grads_host;   // state_dict order: pts_linears.i -> 2i, 2i+1; views 16,17; feature 18,19; alpha 20,21; rgb 22,23
+    // state_dict order: pts_linears.i -> 2i, 2i+1; views_linears.0 16, 17; then with view directions feature 18, 19,
+    // alpha 20, 21, rgb 22, 23; without them output_linear 18, 19 (views_linears.0 is unused and gets no gradient)
+    float* const* g = grads_host;
     int rc;
 #define NERF_TRY(x) do { rc = (x); if (rc != NERF_OK) return rc; } while (0)
     NERF_TRY(launch_wgrad(gt.dz[0], 256, 256, tp.pe, TAPE_PE, 64, M, workspace, g[0], 63, 0, 1, g[1], st));
@@ -399,11 +462,15 @@ extern "C" int nerf_mlp_backward(const void* packed_bwd, const float* d_raw, lon
         NERF_TRY(launch_wgrad(gt.dz[i], 256, 256, tp.h[i - 1], 256, 256, M, workspace, g[2 * i], ld, off, 0, g[2 * i + 1], st));
         if (i == 5) NERF_TRY(launch_wgrad(gt.dz[5], 256, 256, tp.pe, TAPE_PE, 64, M, workspace, g[10], 319, 0, 1, nullptr, st));
     }
-    NERF_TRY(launch_wgrad(gt.dfeat, 256, 256, tp.h[7], 256, 256, M, workspace, g[18], 256, 0, 0, g[19], st));
-    NERF_TRY(launch_wgrad(gt.dzv, 128, 128, tp.feat, 256, 256, M, workspace, g[16], 283, 0, 0, g[17], st));
-    NERF_TRY(launch_wgrad(gt.dzv, 128, 128, tp.vw, TAPE_VW, 32, M, workspace, g[16], 283, 256, 2, nullptr, st));
-    NERF_TRY(launch_wgrad_small(d_raw, 3, 1, tp.h[7], 256, M, workspace, g[20], g[21], st));
-    NERF_TRY(launch_wgrad_small(d_raw, 0, 3, tp.hv, 128, M, workspace, g[22], g[23], st));
+    if (use_viewdirs) {
+        NERF_TRY(launch_wgrad(gt.dfeat, 256, 256, tp.h[7], 256, 256, M, workspace, g[18], 256, 0, 0, g[19], st));
+        NERF_TRY(launch_wgrad(gt.dzv, 128, 128, tp.feat, 256, 256, M, workspace, g[16], 283, 0, 0, g[17], st));
+        NERF_TRY(launch_wgrad(gt.dzv, 128, 128, tp.vw, TAPE_VW, 32, M, workspace, g[16], 283, 256, 2, nullptr, st));
+        NERF_TRY(launch_wgrad_small(d_raw, 4, 3, 1, tp.h[7], 256, M, workspace, g[20], g[21], st));
+        NERF_TRY(launch_wgrad_small(d_raw, 4, 0, 3, tp.hv, 128, M, workspace, g[22], g[23], st));
+    } else {
+        NERF_TRY(launch_wgrad_small(d_raw, output_ch, 0, output_ch, tp.h[7], 256, M, workspace, g[18], g[19], st));
+    }
 #undef NERF_TRY
     return NERF_OK;
 }

@@ -102,30 +102,32 @@ void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// Heads with 1 or 3 outputs (alpha_linear, rgb_linear): G is a column range of d_raw [M,4].  One thread
-// per input feature, samples of the block's range in sequence; X rows are read coalesced, G by broadcast.
+// Heads with up to 5 outputs (alpha_linear, rgb_linear, output_linear): G is a column range of d_raw [M, ldr].  One
+// thread per input feature, samples of the block's range in sequence; X rows are read coalesced, G by broadcast.
+constexpr int WS_MAX_N = 5;
 struct WsmallArgs {
-    const float* d_raw; int c0, N;       // output o <-> d_raw column c0 + o, N <= 3
+    const float* d_raw; int ldr, c0, N;  // output o <-> d_raw column c0 + o, N <= WS_MAX_N
     const float* X; int K;               // [M, K], K = blockDim.x
     long long M, chunk;
-    float* part;                         // [grid][4][K]
-    float* bpart;                        // [grid][4]
+    float* part;                         // [grid][8][K]
+    float* bpart;                        // [grid][8]
 };
 __global__ void wgrad_small_kernel(WsmallArgs a) {
     const int k = threadIdx.x;
     const long long m0 = (long long)blockIdx.x * a.chunk;
     const long long m1 = m0 + a.chunk < a.M ? m0 + a.chunk : a.M;
-    float s[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
+    float s[WS_MAX_N], b[WS_MAX_N];
+#pragma unroll
+    for (int o = 0; o < WS_MAX_N; ++o) s[o] = b[o] = 0.f;
     for (long long m = m0; m < m1; ++m) {
         const float x = a.X[(size_t)m * a.K + k];
-        const float4 g = *reinterpret_cast<const float4*>(a.d_raw + (size_t)m * 4);
-        const float gv[4] = {g.x, g.y, g.z, g.w};
+        const float* g = a.d_raw + (size_t)m * a.ldr + a.c0;
 #pragma unroll
-        for (int o = 0; o < 3; ++o)
-            if (o < a.N) { s[o] = fmaf(gv[a.c0 + o], x, s[o]); b[o] += gv[a.c0 + o]; }
+        for (int o = 0; o < WS_MAX_N; ++o)
+            if (o < a.N) { const float gv = g[o]; s[o] = fmaf(gv, x, s[o]); b[o] += gv; }
     }
-    for (int o = 0; o < a.N; ++o) a.part[((size_t)blockIdx.x * 4 + o) * a.K + k] = s[o];
-    if (k == 0) for (int o = 0; o < a.N; ++o) a.bpart[(size_t)blockIdx.x * 4 + o] = b[o];
+    for (int o = 0; o < a.N; ++o) a.part[((size_t)blockIdx.x * 8 + o) * a.K + k] = s[o];
+    if (k == 0) for (int o = 0; o < a.N; ++o) a.bpart[(size_t)blockIdx.x * 8 + o] = b[o];
 }
 
 // dst[row * ld + col_off + map(col)] = sum over parts, in part order.  map: 0 identity, 1 encoded-point
@@ -188,23 +190,23 @@ int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K,
     return NERF_OK;
 }
 
-int launch_wgrad_small(const float* d_raw, int c0, int N, const float* X, int K, long long M, float* ws,
-                              float* dW, float* db, hipStream_t st) {
+int launch_wgrad_small(const float* d_raw, int ldr, int c0, int N, const float* X, int K, long long M, float* ws,
+                       float* dW, float* db, hipStream_t st) {
+    NERF_REQUIRE(N >= 1 && N <= WS_MAX_N && K <= 256, "weight gradient (head): unsupported shape %d x %d", N, K);
     long long parts = (M + 255) / 256;
     if (parts > 1024) parts = 1024;
     const long long chunk = (M + parts - 1) / parts;
     parts = (M + chunk - 1) / chunk;
-    WsmallArgs a{d_raw, c0, N, X, K, M, chunk, ws, ws + (size_t)1024 * 4 * 256};
+    WsmallArgs a{d_raw, ldr, c0, N, X, K, M, chunk, ws, ws + (size_t)1024 * 8 * 256};
     hipLaunchKernelGGL(wgrad_small_kernel, dim3((unsigned)parts), dim3(K), 0, st, a);
     NERF_LAUNCH_CHECK();
-    ReduceArgs r{ws, (int)parts, 4, K, N, K, dW, K, 0, 0};
+    ReduceArgs r{ws, (int)parts, 8, K, N, K, dW, K, 0, 0};
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K + 63) / 64, N), dim3(64), 0, st, r);
     NERF_LAUNCH_CHECK();
-    ReduceArgs rb{a.bpart, (int)parts, 1, 4, 1, N, db, N, 0, 0};
+    ReduceArgs rb{a.bpart, (int)parts, 1, 8, 1, N, db, N, 0, 0};
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1, 1), dim3(64), 0, st, rb);
     NERF_LAUNCH_CHECK();
     return NERF_OK;
 }
-
 
 }  // namespace nerf

@@ -11,55 +11,73 @@ torch.autograd.Function nodes wrap hand-written HIP kernels:
   _CompositeFn  raw2outputs: closed-form backward of the alpha compositing
 
 Training always computes in float32 (like the reference), whatever the
-``precision`` attribute says about inference.  Only the view-dependent
-architecture (use_viewdirs=True, the one every config of the reference trains)
-is implemented; others raise NotImplementedError.  Nothing here falls back to
-autograd over torch ops.
+``precision`` attribute says about inference.  The architecture is the one the
+inference kernels implement (D=8, W=256, skips=[4], with view directions or
+without and output_ch 4 / 5); others raise NotImplementedError.  Nothing here
+falls back to autograd over torch ops.
 """
 import numpy as np
 import torch
 
 from . import hip
 
-_PARAM_ORDER = (["pts_linears.%d.%s" % (i, k) for i in range(8) for k in ("weight", "bias")] +
-                ["views_linears.0.weight", "views_linears.0.bias", "feature_linear.weight", "feature_linear.bias",
-                 "alpha_linear.weight", "alpha_linear.bias", "rgb_linear.weight", "rgb_linear.bias"])
+_TRUNK = ["pts_linears.%d.%s" % (i, k) for i in range(8) for k in ("weight", "bias")]
+_PARAM_ORDER = {True: _TRUNK + ["views_linears.0.weight", "views_linears.0.bias", "feature_linear.weight",
+                                "feature_linear.bias", "alpha_linear.weight", "alpha_linear.bias", "rgb_linear.weight",
+                                "rgb_linear.bias"],
+                # without view directions views_linears.0 exists in the module but is never used: no gradient
+                False: _TRUNK + [None, None, "output_linear.weight", "output_linear.bias"]}
 
 
 def _params(model):
-    if not (model.use_viewdirs and model.hip_supported()):
-        raise NotImplementedError("training kernels implement the view-dependent network only (use_viewdirs=True, "
-                                  "D=8, W=256, skips=[4], input_ch=63, input_ch_views=27)")
+    """Parameters in the kernels' tensor order (None for unused slots)."""
+    if not model.hip_supported():
+        raise NotImplementedError("training kernels implement D=8, W=256, skips=[4], input_ch=63 (and input_ch_views=27 "
+                                  "with view directions, output_ch 4 or 5 without)")
     named = dict(model.named_parameters())
-    return [named[k] for k in _PARAM_ORDER]
+    return [None if k is None else named[k] for k in _PARAM_ORDER[bool(model.use_viewdirs)]]
 
 
 def _packed_backward(model, params):
     """Transposed-weight stream for the input-gradient chain, cached per weight version."""
-    key = (hip.WEIGHT_GENERATION[0],) + tuple((p.data_ptr(), p._version) for p in params)
+    key = (hip.WEIGHT_GENERATION[0],) + tuple((p.data_ptr(), p._version) for p in params if p is not None)
     hit = model._pack_cache.get("bwd")
     if hit is not None and hit[0] == key:
         return hit[1]
-    packed = hip.mlp_pack_backward([p.detach() for p in params])
+    packed = hip.mlp_pack_backward([None if p is None else p.detach() for p in params], model.use_viewdirs,
+                                   model.out_channels)
     model._pack_cache["bwd"] = (key, packed)
     return packed
 
 
 class _NetworkFn(torch.autograd.Function):
+    """inputs: model, slot map, input mode and tensors, then the parameter tensors that exist (unused slots of the
+    kernels' tensor order are left out: autograd cannot take None where a gradient is returned)."""
+
     @staticmethod
-    def forward(ctx, model, mode, in0, in1, R, S, ray_cols, *params):
+    def forward(ctx, model, slots, mode, in0, in1, R, S, ray_cols, *params):
+        full = [None] * len(slots)
+        for p, i in zip(params, [i for i, used in enumerate(slots) if used]):
+            full[i] = p
         packed = model.packed_weights(hip.PREC_F32)
-        raw, tape = hip.mlp_forward_train(packed, mode, in0, in1, R, S, ray_cols)
+        raw, tape = hip.mlp_forward_train(packed, model.use_viewdirs, model.out_channels, mode, in0, in1, R, S, ray_cols)
         ctx.tape = tape
-        ctx.packed_bwd = _packed_backward(model, params)
-        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.packed_bwd = _packed_backward(model, full)
+        ctx.shapes = [None if p is None else tuple(p.shape) for p in full]
+        ctx.arch = (model.use_viewdirs, model.out_channels)
         return raw
 
     @staticmethod
     def backward(ctx, g_raw):
-        grads = hip.mlp_backward(ctx.packed_bwd, g_raw.contiguous(), ctx.tape, ctx.shapes)
+        grads = hip.mlp_backward(ctx.packed_bwd, ctx.arch[0], ctx.arch[1], g_raw.contiguous(), ctx.tape, ctx.shapes)
         ctx.tape = None
-        return (None,) * 7 + tuple(grads)
+        return (None,) * 8 + tuple(g for g in grads if g is not None)
+
+
+def _network(model, mode, in0, in1, R, S, ray_cols):
+    params = _params(model)
+    slots = tuple(p is not None for p in params)
+    return _NetworkFn.apply(model, slots, mode, in0, in1, R, S, ray_cols, *[p for p in params if p is not None])
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -90,25 +108,26 @@ def _no_input_grad(t, what):
 def mlp_forward_autograd(model, x):
     """NeRF.forward on encoded features [..., 90] with parameter gradients."""
     _no_input_grad(x, "the encoded network input")
-    params = _params(model)
-    flat = x.reshape(-1, x.shape[-1])[:, :90].contiguous().float()
-    out = _NetworkFn.apply(model, hip.IN_FEATURES, flat, None, flat.shape[0], 1, 0, *params)
-    return out.reshape(tuple(x.shape[:-1]) + (4,))
+    ch = 90 if model.use_viewdirs else 63
+    flat = x.reshape(-1, x.shape[-1])[:, :ch].contiguous().float()
+    out = _network(model, hip.IN_FEATURES, flat, None, flat.shape[0], 1, 0)
+    return out.reshape(tuple(x.shape[:-1]) + (model.out_channels,))
 
 
 def run_network_autograd(inputs, viewdirs, fn):
     """run_network (run_nerf.py:37-51) with the encodings fused, parameter gradients only."""
     _no_input_grad(inputs, "inputs")
     _no_input_grad(viewdirs, "viewdirs")
-    params = _params(fn)
     S = inputs.shape[-2] if inputs.dim() >= 2 else 1
     pts = inputs.reshape(-1, 3).contiguous().float()
     R = pts.shape[0] // S
-    vd = viewdirs.reshape(-1, 3).contiguous().float()
-    if vd.shape[0] != R:
-        raise ValueError("viewdirs has %d rows for %d rays" % (vd.shape[0], R))
-    out = _NetworkFn.apply(fn, hip.IN_POINTS, pts, vd, R, S, 0, *params)
-    return out.reshape(list(inputs.shape[:-1]) + [4])
+    vd = None
+    if fn.use_viewdirs:
+        vd = viewdirs.reshape(-1, 3).contiguous().float()
+        if vd.shape[0] != R:
+            raise ValueError("viewdirs has %d rows for %d rays" % (vd.shape[0], R))
+    out = _network(fn, hip.IN_POINTS, pts, vd, R, S, 0)
+    return out.reshape(list(inputs.shape[:-1]) + [fn.out_channels])
 
 
 def raw2outputs_autograd(raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest):
@@ -140,7 +159,7 @@ def render_rays_autograd(rays, z_vals, network_fn, network_query_fn, N_samples, 
         needs = isinstance(net, torch.nn.Module) and any(p.requires_grad for p in net.parameters())
         if fused and network_query_fn.fusable(net, has_vd):
             if needs:
-                out = _NetworkFn.apply(net, hip.IN_RAYS, rays, z, N_rays, z.shape[1], cols, *_params(net))
+                out = _network(net, hip.IN_RAYS, rays, z, N_rays, z.shape[1], cols)
             else:
                 prec = net.precision_code()
                 out = hip.mlp_forward(net.packed_weights(prec), prec, net.use_viewdirs, net.out_channels, hip.IN_RAYS,

@@ -386,9 +386,10 @@ def raw2outputs_backward(raw, z_vals, rays_d, noise=None, white_bkgd=False, g_rg
     return out
 
 
-def mlp_backward(sd, feat, d_raw):
-    """Gradients of the 24 parameter tensors of the view-dependent network for dL/draw = d_raw [N,4], float64.
-    Returns {state_dict name: gradient}."""
+def mlp_backward(sd, feat, d_raw, use_viewdirs=True):
+    """Gradients of the parameter tensors for dL/draw = d_raw [N, C], float64 (C = 4 with view directions, else the
+    rows of output_linear).  Returns {state_dict name: gradient}; the view branch is pinned by the reference's
+    autograd gradients (g8), the branch without view directions shares the trunk and has no reference fixture."""
     f = np.float64
     W = {k: v.astype(f) for k, v in sd.items()}
     x = feat.astype(f)
@@ -403,20 +404,24 @@ def mlp_backward(sd, feat, d_raw):
         if i == 4:
             h = np.concatenate([pts, h], -1)
     h8 = h
-    feature = h8 @ W["feature_linear.weight"].T + W["feature_linear.bias"]
-    hv_in = np.concatenate([feature, views], -1)
-    hv_pre = hv_in @ W["views_linears.0.weight"].T + W["views_linears.0.bias"]
-    hv = np.maximum(hv_pre, 0)
     g = {}
     d = d_raw.astype(f)
-    d_rgb, d_sig = d[:, :3], d[:, 3:4]
-    g["rgb_linear.weight"], g["rgb_linear.bias"] = d_rgb.T @ hv, d_rgb.sum(0)
-    d_hv = (d_rgb @ W["rgb_linear.weight"]) * (hv_pre > 0)
-    g["views_linears.0.weight"], g["views_linears.0.bias"] = d_hv.T @ hv_in, d_hv.sum(0)
-    d_feat = (d_hv @ W["views_linears.0.weight"])[:, :256]
-    g["feature_linear.weight"], g["feature_linear.bias"] = d_feat.T @ h8, d_feat.sum(0)
-    g["alpha_linear.weight"], g["alpha_linear.bias"] = d_sig.T @ h8, d_sig.sum(0)
-    dh = d_feat @ W["feature_linear.weight"] + d_sig @ W["alpha_linear.weight"]
+    if use_viewdirs:
+        feature = h8 @ W["feature_linear.weight"].T + W["feature_linear.bias"]
+        hv_in = np.concatenate([feature, views], -1)
+        hv_pre = hv_in @ W["views_linears.0.weight"].T + W["views_linears.0.bias"]
+        hv = np.maximum(hv_pre, 0)
+        d_rgb, d_sig = d[:, :3], d[:, 3:4]
+        g["rgb_linear.weight"], g["rgb_linear.bias"] = d_rgb.T @ hv, d_rgb.sum(0)
+        d_hv = (d_rgb @ W["rgb_linear.weight"]) * (hv_pre > 0)
+        g["views_linears.0.weight"], g["views_linears.0.bias"] = d_hv.T @ hv_in, d_hv.sum(0)
+        d_feat = (d_hv @ W["views_linears.0.weight"])[:, :256]
+        g["feature_linear.weight"], g["feature_linear.bias"] = d_feat.T @ h8, d_feat.sum(0)
+        g["alpha_linear.weight"], g["alpha_linear.bias"] = d_sig.T @ h8, d_sig.sum(0)
+        dh = d_feat @ W["feature_linear.weight"] + d_sig @ W["alpha_linear.weight"]
+    else:
+        g["output_linear.weight"], g["output_linear.bias"] = d.T @ h8, d.sum(0)
+        dh = d @ W["output_linear.weight"]
     for i in range(7, -1, -1):
         dz = dh * (pre[i] > 0)
         g["pts_linears.%d.weight" % i], g["pts_linears.%d.bias" % i] = dz.T @ ins[i], dz.sum(0)
