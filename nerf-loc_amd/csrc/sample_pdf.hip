@@ -108,12 +108,16 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void sample_pdf_kernel(SamplePdfArg
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nb = a.nb, nw = a.nb - 1, n_u = a.n_u, n_z = a.z_sorted ? a.n_z : 0;
     const int sw = nw | 1, sc = nb | 1;                       // odd row strides
-    const int per_wave = PDF_GROUP * (sw + sc) + nb + n_u + n_z;
+    const int per_wave = PDF_GROUP * (sw + sc) + nb + 2 * n_u + n_z;
     float* w_g = smem + (size_t)wv * per_wave;                // [PDF_GROUP][sw] weights + 1e-5
     float* cdf_g = w_g + PDF_GROUP * sw;                      // [PDF_GROUP][sc]
     float* bins_s = cdf_g + PDF_GROUP * sc;                   // the ray in flight: bins, samples, coarse depths
     float* zs_s = bins_s + nb;
     float* zc_s = zs_s + n_u;
+    int* ind_s = reinterpret_cast<int*>(zc_s + n_z);          // searchsorted results of the ray in flight
+    // coarse depths and bins come from the same array: the rank of a sample among the coarse depths follows from
+    // its bin (checked, with the binary search as fallback)
+    const bool z_is_bins = a.bins_are_z && a.z_sorted && a.z_vals == a.bins && a.n_z == nb + 1;
     const long long r0 = ((long long)blockIdx.x * PDF_WAVES + wv) * PDF_GROUP;
     const long long last = a.R - 1;
 
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void sample_pdf_kernel(SamplePdfArg
             const float bb = bins_s[below], ba = bins_s[above];
             const float s = fadd(bb, fmul(t, fsub(ba, bb)));
             zs_s[j] = s;
+            ind_s[j] = ind;
             lsum += s;
             if (live) {
                 if (a.z_samples) a.z_samples[(size_t)ray * n_u + j] = s;
@@ -205,8 +210,16 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void sample_pdf_kernel(SamplePdfArg
                 }
                 for (int j = lane; j < n_u; j += WAVE) {
                     const float v = zs_s[j];
-                    const int r = j + count_sorted<true>(zc_s, n_z, v);
-                    if (live) out[r] = v;
+                    int rc = -1;
+                    if (z_is_bins) {
+                        // v lies between the mid-points around coarse depth number ind: ind or ind + 1 depths are <= v
+                        const int ind = ind_s[j];
+                        const int c = ind + ((ind < n_z && zc_s[ind] <= v) ? 1 : 0);
+                        const bool ok = (c == 0 || zc_s[c - 1] <= v) && (c == n_z || zc_s[c] > v);
+                        if (ok) rc = c;
+                    }
+                    if (rc < 0) rc = count_sorted<true>(zc_s, n_z, v);
+                    if (live) out[j + rc] = v;
                 }
             } else {
                 for (int i = lane; i < n_z; i += WAVE) {
@@ -246,7 +259,7 @@ extern "C" int nerf_sample_pdf(const float* bins, int bins_stride, int bins_are_
     if (R == 0) return NERF_OK;
     SamplePdfArgs a{bins, bins_stride, bins_are_z, nb, weights, w_stride, u, n_u, u_per_ray, R,
                     z_vals, n_z, z_samples, inds, z_sorted, z_std};
-    const size_t per_wave = (size_t)PDF_GROUP * (((nb - 1) | 1) + (nb | 1)) + nb + n_u + (z_sorted ? n_z : 0);
+    const size_t per_wave = (size_t)PDF_GROUP * (((nb - 1) | 1) + (nb | 1)) + nb + 2 * (size_t)n_u + (z_sorted ? n_z : 0);
     const size_t shmem = per_wave * PDF_WAVES * sizeof(float);
     NERF_REQUIRE(shmem <= 64 * 1024, "nerf_sample_pdf: rows too long for the LDS staging (%zu bytes)", shmem);
     const int rays_per_block = PDF_WAVES * PDF_GROUP;
