@@ -132,7 +132,10 @@ int nerf_sample_pdf(const float* bins, int bins_stride, int bins_are_z, int nb,
  * The reference trains through PyTorch autograd (run_nerf.py:770-796: render -> img2mse ->
  * loss.backward() -> Adam).  These entry points produce what autograd would: gradients of a
  * scalar loss with respect to raw (compositing) and to the 24 parameter tensors (network), for
- * the D=8 / W=256 architecture (with or without view directions) in float32.
+ * the D=8 / W=256 architecture (with or without view directions).  `precision` selects the
+ * arithmetic of the network kernels: NERF_PREC_F32 (exact float32 MFMA) or NERF_PREC_BF16 (bf16
+ * operands, float32 accumulation; parameters and gradients stay float32).  Tapes, packed
+ * streams and entry points of one training step must all use the same precision.
  *
  * nerf_raw2outputs_backward: backward of raw2outputs (run_nerf.py:268-311).  g_rgb [R,3], g_disp,
  * g_acc, g_depth [R] are the upstream gradients of the maps (any may be NULL = zero); d_raw
@@ -144,32 +147,34 @@ int nerf_raw2outputs_backward(const float* raw, int raw_ch, const float* z_vals,
 
 /* Buffers the caller owns: the activation tape written by the training forward and read by
  * the backward, the gradient tape (scratch of the backward), and a fixed-size workspace.     */
-size_t nerf_train_tape_bytes(long long M, int use_viewdirs);
-size_t nerf_train_grad_tape_bytes(long long M, int use_viewdirs);
+size_t nerf_train_tape_bytes(long long M, int use_viewdirs, int precision);
+size_t nerf_train_grad_tape_bytes(long long M, int use_viewdirs, int precision);
 size_t nerf_train_workspace_bytes(void);
 
-/* nerf_mlp_forward in NERF_PREC_F32 that also fills `tape` (NeRF.forward with autograd
- * recording, run_nerf_helpers.py:96-119).  `packed` comes from nerf_mlp_pack(...,
- * NERF_PREC_F32, ...) for the same use_viewdirs / output_ch.                                 */
-int nerf_mlp_forward_train(const void* packed, int use_viewdirs, int output_ch, int input_mode,
-                           const float* in0, const float* in1, int R, int S, int ray_cols,
-                           float* raw_out, float* tape, void* stream);
+/* nerf_mlp_forward that also fills `tape` (NeRF.forward with autograd recording,
+ * run_nerf_helpers.py:96-119).  `packed` comes from nerf_mlp_pack for the same precision,
+ * use_viewdirs and output_ch.                                                                */
+int nerf_mlp_forward_train(const void* packed, int precision, int use_viewdirs, int output_ch,
+                           int input_mode, const float* in0, const float* in1, int R, int S,
+                           int ray_cols, float* raw_out, void* tape, void* stream);
 
 /* Transposed weights for the input-gradient chain; same tensors_host as nerf_mlp_pack (biases
  * ignored).  Re-pack whenever the weights change.                                             */
-size_t nerf_mlp_backward_packed_bytes(int use_viewdirs);
+size_t nerf_mlp_backward_packed_bytes(int use_viewdirs, int precision);
 int nerf_mlp_pack_backward(const float* const* tensors_host, int use_viewdirs, int output_ch,
-                           void* packed_out, void* stream);
+                           int precision, void* packed_out, void* stream);
 
 /* Gradients of the parameter tensors given d_raw [M, output_ch] = dL/draw (M = R*S of the
  * forward).  grads_host: HOST array of device pointers in state_dict order (24 with view
  * directions, 20 without: entries 16, 17 = views_linears.0 are then unused and may be NULL),
  * each shaped like its parameter; every element is overwritten (not accumulated).
  * Deterministic: partial sums are combined in a fixed order.  No gradient is produced for the
- * network inputs.                                                                             */
-int nerf_mlp_backward(const void* packed_bwd, int use_viewdirs, int output_ch, const float* d_raw,
-                      long long M, const float* tape, float* grad_tape, float* workspace,
-                      size_t workspace_bytes, float* const* grads_host, void* stream);
+ * network inputs.  packed_fwd: the forward stream of nerf_mlp_pack the tape was made with
+ * (read in NERF_PREC_BF16 only, for its activation scales; may be NULL in NERF_PREC_F32).     */
+int nerf_mlp_backward(const void* packed_bwd, const void* packed_fwd, int precision, int use_viewdirs,
+                      int output_ch, const float* d_raw, long long M, const void* tape,
+                      void* grad_tape, float* workspace, size_t workspace_bytes,
+                      float* const* grads_host, void* stream);
 
 /* One Adam update of up to 64 parameter tensors in a single launch: torch.optim.Adam as the
  * reference constructs it (run_nerf.py:225, betas (0.9, 0.999), eps 1e-8, no amsgrad), the

@@ -16,135 +16,12 @@
 //   * positions (o + d z), sin/cos features and the per-ray view encoding are computed in
 //     registers from 44 B/ray + 4 B/sample; nothing but raw[.,4] is written back.
 // Bound: MFMA.  1 186 816 algorithmic FLOP per sample (1 212 416 issued with padding).
-#include "mlp_device.h"
+#include <type_traits>
+#include "mlp_bf16.h"
+#include "train_bf16.h"
 
 namespace nerf {
 
-
-// ------------------------------------------------------------------------------------------
-// bf16 kernel: 2 column tiles (64 samples) per wave, software-pipelined by hand:
-//   * weight fragments are read from LDS PF k-steps ahead into a 4-deep register queue;
-//   * the epilogue of an output tile (relu + v_cvt_pk_bf16_f32 into the next layer's operand
-//     registers) is cut into 16 slices that are issued under the MFMAs of the NEXT tile;
-//   * the bias of the next tile is fetched half a tile ahead.
-// The running position `pos` in the fragment stream is a compile-time constant everywhere
-// (everything below is fully unrolled), only ring slots and addresses are run-time values.
-// ------------------------------------------------------------------------------------------
-constexpr int NCT = 2;
-#ifndef NERF_PF
-#define NERF_PF 3
-#endif
-constexpr int PF = NERF_PF;                  // LDS read-ahead in fragments
-constexpr int QD = PF + 1 <= 4 ? 4 : 8;      // queue depth (power of two > PF)
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-struct Stream {                              // position-independent view of the LDS ring
-    Pipe p;
-    unsigned slot0;                          // ring slot of stage 0 of the current pass
-    u32x4 q[QD];                             // fragment queue: q[k & (QD-1)] holds fragment k
-
-    __device__ __forceinline__ const unsigned char* addr(int k) const {
-        const unsigned slot = (slot0 + (unsigned)(k >> 4)) & (NSTAGE - 1);
-        return p.lds + slot * STAGE_BYTES + (k & (STAGE_FRAGS - 1)) * FRAG_BYTES + p.lane16;
-    }
-    __device__ __forceinline__ void fetch(int k) { q[k & (QD - 1)] = *reinterpret_cast<const u32x4*>(addr(k)); }
-    // before fragment `pos` is consumed: at mid-stage make the next stage visible
-    __device__ __forceinline__ void tick(int pos) {
-        if ((pos & (STAGE_FRAGS - 1)) == STAGE_FRAGS / 2) p.advance();
-    }
-    __device__ __forceinline__ void end_pass(int n_frags) { slot0 = (slot0 + (unsigned)(n_frags >> 4)) & (NSTAGE - 1); }
-};
-
-__device__ __forceinline__ unsigned pack_pair(float a, float b, bool relu) {
-    if (relu) {
-        // Activations are stored scaled into [0, 1) (mlp_layout.h, scale_kernel): the clamp bit of the conversion
-        // (saturate to [0, 1], negatives and -0 to +0) is then ReLU, at no extra instruction.
-        unsigned r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-        return r;
-    }
-    const f32x2 f = {a, b};
-    const bf16x2 v = __builtin_convertvector(f, bf16x2);   // one v_cvt_pk_bf16_f32
-    return __builtin_bit_cast(unsigned, v);
-}
-
-// slice sl (0..15) of the epilogue of a finished tile: two accumulator registers -> one packed
-// operand dword of the next layer.  dst = &h[2t]: rows 2t <- registers 0-7, 2t+1 <- registers 8-15.
-__device__ __forceinline__ void epi_slice(const f32x16 (&accp)[NCT], u32x4 (*dst)[NCT], bool relu, int sl) {
-    const int g = sl >> 2, qd = sl & 3, ct = g >> 1, half = g & 1;
-    dst[half][ct][qd] = pack_pair(accp[ct][8 * half + 2 * qd], accp[ct][8 * half + 2 * qd + 1], relu);
-}
-
-// One 32-row output tile: k-steps [pe KPE][hidden KH][view KVW] accumulate into `acc`, while the
-// epilogue of the previous tile (accumulators `accp`, destination pdst) is issued, if has_prev.
-// The two accumulator sets alternate from tile to tile, so nothing is ever copied.
-template <int KPE, int KH, int KVW, bool early>
-__device__ __forceinline__ void tile_bf16(Stream& st, int pos, int h, int bias_next_idx, f32x16& bias,
-                                          const u32x4 (*pe)[NCT], const u32x4 (*hin)[NCT], const u32x4 (*vw)[NCT],
-                                          f32x16 (&acc)[NCT], const f32x16 (&accp)[NCT], u32x4 (*pdst)[NCT],
-                                          bool prelu, bool has_prev) {
-    constexpr int KS = KPE + KH + KVW;
-    // The 16 epilogue slices of the previous tile are spread over k-steps 1..EPI_N (the previous
-    // tile's last MFMA result is not readable for a few cycles, hence not k-step 0).  When this
-    // tile reads what the epilogue writes (first tile of a layer: rows 14, 15 of its input) it must
-    // be done early, otherwise it may take the whole tile: at most one slice per MFMA gap.
-    constexpr int EPI_N = early ? (KS >= 16 ? 12 : KS / 2) : KS - 1;
-    f32x16 bias_next = bias;
-    // The order below is the issue order: hipcc's scheduler would otherwise sink every LDS read
-    // next to its MFMA (one s_waitcnt lgkmcnt(0) per k-step) and bunch the epilogue in front of the
-    // tile, so each group is fenced with sched_barrier(0).  Per k-step: 1 ds_read_b128 (PF ahead),
-    // MFMA, <= 8 VALU of the previous tile's epilogue, MFMA, <= 8 VALU.
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int k = pos + s;
-        st.tick(k);
-        __builtin_amdgcn_sched_barrier(0);
-        st.fetch(k + PF);
-        if (s == KS / 2) bias_next = bias_tile(st.p.lds, bias_next_idx, h);
-        __builtin_amdgcn_sched_barrier(0);
-        const u32x4* b = s < KPE ? pe[s] : (s < KPE + KH ? hin[s - KPE] : vw[s - KPE - KH]);
-        const bf16x8 w = __builtin_bit_cast(bf16x8, st.q[k & (QD - 1)]);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, __builtin_bit_cast(bf16x8, b[ct]),
-                                                             s == 0 ? bias : acc[ct], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_prev && s >= 1 && s <= EPI_N) {
-                const int lo = (16 * (s - 1) + EPI_N - 1) / EPI_N, hi = (16 * s + EPI_N - 1) / EPI_N;
-                const int cnt = (hi < 16 ? hi : 16) - lo, first = cnt / 2;   // ct0 gap: first, ct1 gap: the rest
-                const int b0 = ct == 0 ? lo : lo + first, b1 = ct == 0 ? lo + first : lo + cnt;
-#pragma unroll
-                for (int sl = b0; sl < b1; ++sl) epi_slice(accp, pdst, prelu, sl);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    bias = bias_next;
-}
-
-// NT tiles of one layer.  (prev_dst, prev_relu, has_prev) describe the tile that ran just before
-// this layer; tile number bt of the pass accumulates into accs[bt & 1]; on return the last tile of this
-// layer is pending there (destination hout + 2(NT-1)).
-template <int NT, int KPE, int KH, int KVW>
-__device__ __forceinline__ void layer_bf16(Stream& st, int& pos, int& bt, int n_bias_tiles, int h, f32x16& bias,
-                                           const u32x4 (*pe)[NCT], const u32x4 (*hin)[NCT], const u32x4 (*vw)[NCT],
-                                           f32x16 (&accs)[2][NCT], u32x4 (*prev_dst)[NCT], bool prev_relu, bool has_prev,
-                                           u32x4 (*hout)[NCT], bool relu) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (t == 0)
-            tile_bf16<KPE, KH, KVW, true>(st, pos, h, (bt + 1) % n_bias_tiles, bias, pe, hin, vw, accs[bt & 1],
-                                          accs[(bt & 1) ^ 1], prev_dst, prev_relu, has_prev);
-        else
-            tile_bf16<KPE, KH, KVW, false>(st, pos, h, (bt + 1) % n_bias_tiles, bias, pe, hin, vw, accs[bt & 1],
-                                           accs[(bt & 1) ^ 1], hout + 2 * (t - 1), relu, true);
-        pos += KPE + KH + KVW;
-        bt += 1;
-    }
-}
 
 #ifdef NERF_EXP_STAMP
 // diagnostic build only: per-block cycle sums {input+encoding, layers 0-4, layer 5-7, heads, store, passes}
@@ -157,7 +34,18 @@ __device__ unsigned long long g_stamps[256 * 8];
 #define NERF_STAMP(var)
 #endif
 
-template <bool VD, int OUT_CH>
+// TAPE: the training forward.  Every layer input a weight gradient needs is also stored, in the operand layout it
+// has in the registers (train_bf16.h).
+struct EpiTape {
+    static constexpr bool ZERO_BIAS = false;
+    __device__ __forceinline__ void prefetch(const EpiTile&, int) {}
+    __device__ __forceinline__ unsigned post(unsigned v, const EpiTile&, int, int, int, int) const { return v; }
+    __device__ __forceinline__ void store(const u32x4& v, const EpiTile& t, int half, int ct) const {
+        if (t.has_out) *reinterpret_cast<u32x4*>(t.out + (half * 2 + ct) * 1024) = v;
+    }
+};
+
+template <bool VD, int OUT_CH, bool TAPE>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp_bf16_kernel(MlpArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
@@ -224,35 +112,59 @@ void mlp_bf16_kernel(MlpArgs a) {
         }
 
         NERF_STAMP(t1)
+        // tape of this wave's 64 samples (training forward): piece p at tw + p * 2 KiB, lane quad at + ct KiB
+        unsigned char* tw = nullptr;
+        if (TAPE) {
+            const unsigned long long blk = (unsigned long long)(tile * 4 + wave) * (tape16::total(VD) * tape16::PIECE_BYTES);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)blk), hi = __builtin_amdgcn_readfirstlane((unsigned)(blk >> 32));
+            tw = a.tape + (((unsigned long long)hi << 32) | lo) + lane * 16;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    *reinterpret_cast<u32x4*>(tw + (tape16::PE + ks) * tape16::PIECE_BYTES + ct * 1024) = pe[ks][ct];
+                if (VD) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        *reinterpret_cast<u32x4*>(tw + (tape16::VW + ks) * tape16::PIECE_BYTES + ct * 1024) = vw[ks][ct];
+                }
+            }
+        }
+        typename std::conditional<TAPE, EpiTape, EpiNone>::type epi;
+        EpiTile carry{nullptr, nullptr, false, false};
+        auto out = [&](int piece) { return tw + piece * tape16::PIECE_BYTES; };
+#define NERF_L(NT, KPE, KH, KVW, hin, pdst, prelu, hasp, hout, relu, piece, store)                                     \
+    layer_bf16<NT, KPE, KH, KVW>(st, pos, bt, NB, h, bias, pe, hin, vw, accp, pdst, prelu, hasp, hout, relu, epi, carry, \
+                                 nullptr, false, out(piece), TAPE && (store))
         u32x4 A[16][NCT], B[16][NCT];
         f32x16 accp[2][NCT];     // accumulators of the current and of the previous output tile
         int pos = 0, bt = 0;
-        layer_bf16<8, 4, 0, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A, false, false, A, true);         // L0: pe -> A
-        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L1
-        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, true);     // L2
-        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L3
-        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, true);     // L4
+        NERF_L(8, 4, 0, 0, A, A, false, false, A, true, tape16::h(VD, 0), true);        // L0: pe -> A
+        NERF_L(8, 0, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 1), true);    // L1
+        NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, true, tape16::h(VD, 2), true);    // L2
+        NERF_L(8, 0, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 3), true);    // L3
+        NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, true, tape16::h(VD, 4), true);    // L4
         NERF_STAMP(t2)
-        layer_bf16<8, 4, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L5: [pe, h]
-        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, true);     // L6
-        layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A + 14, true, true, B, true);     // L7 -> B
+        NERF_L(8, 4, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 5), true);    // L5: [pe, h]
+        NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, true, tape16::h(VD, 6), true);    // L6
+        NERF_L(8, 0, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 7), true);    // L7 -> B
 
         NERF_STAMP(t3)
         float o0[NCT], o1[NCT], o2[NCT], o3[NCT], o4[NCT];
         if (VD) {
-            layer_bf16<8, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, A, false);   // feature -> A (no relu)
-            layer_bf16<1, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, A + 14, false, true, A, false);  // alpha: row 3
+            NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, false, tape16::FEAT, true);   // feature -> A (no relu)
+            NERF_L(1, 0, 16, 0, B, A + 14, false, true, A, false, 0, false);            // alpha: row 3
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) o3[ct] = accp[(bt - 1) & 1][ct][3];
-            layer_bf16<4, 0, 16, 2>(st, pos, bt, NB, h, bias, pe, A, vw, accp, A, false, false, B, true);       // views -> B[0..7]
-            layer_bf16<1, 0, 8, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 6, true, true, B, false);     // rgb: rows 0..2
+            NERF_L(4, 0, 16, 2, A, A, false, false, B, true, tape16::HV, true);         // views -> B[0..7]
+            NERF_L(1, 0, 8, 0, B, B + 6, true, true, B, false, 0, false);               // rgb: rows 0..2
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const f32x16& r = accp[(bt - 1) & 1][ct];
                 o0[ct] = r[0]; o1[ct] = r[1]; o2[ct] = r[2]; o4[ct] = 0.f;
             }
         } else {
-            layer_bf16<1, 0, 16, 0>(st, pos, bt, NB, h, bias, pe, B, vw, accp, B + 14, true, true, B, false);
+            NERF_L(1, 0, 16, 0, B, B + 14, true, true, B, false, 0, false);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const f32x16& r = accp[(bt - 1) & 1][ct];
@@ -260,6 +172,7 @@ void mlp_bf16_kernel(MlpArgs a) {
                 o4[ct] = r[0];   // row 4 sits in register 0 of the upper lane half
             }
         }
+#undef NERF_L
         st.end_pass(NFRAGS);
         NERF_STAMP(t4)
 #pragma unroll
@@ -384,25 +297,45 @@ __device__ __forceinline__ const float* pack_row(const PackArgs& a, const LayerD
     }
 }
 
-// Output scales of the bf16 network, one block.  B_l bounds |pre-activation| of layer l for any input with
+// Output scales of the bf16 network.  B_l bounds |pre-activation| of layer l for any input with
 // |feature| <= INPUT_BOUND: B_l = max_row (|b| + sum_j |W_j| * bound of input j).  The stored activations are
 // s_l * relu(.) with s_l = 2^-ceil(log2(2 B_l)) < 1 / (2 B_l): the factor 2 covers the bf16 rounding of weights
 // and activations.  Powers of two commute with every rounding step, so the network's results do not change.
-__global__ __launch_bounds__(256) void scale_kernel(PackArgs a, float* scales) {
+// Two launches: per-row sums of |W| (every row of every layer in parallel, a wave per row), then the short chain
+// over the layers in one block.
+__global__ __launch_bounds__(256) void rowsum_kernel(PackArgs a, float* rs /*[layer][256][2]*/) {
+    const int li = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const LayerDesc& L = a.net.layer[li];
+    for (int k = 0; k < 8; ++k) {
+        const int row = blockIdx.y * 32 + wave * 8 + k;
+        if (row >= L.out_dim) break;                          // wave-uniform
+        const float* W = a.t[L.w_idx] + (size_t)row * L.in_dim;
+        float hid = 0.0f, other = 0.0f;
+        for (int col = lane; col < L.in_dim; col += 64) {
+            const float w = fabsf(W[col]);
+            if (col >= L.hid_col && col < L.hid_col + L.hid_feats) hid += w; else other += w;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            hid += __shfl_xor(hid, off, WAVE);
+            other += __shfl_xor(other, off, WAVE);
+        }
+        if (lane == 0) {
+            rs[((size_t)li * 256 + row) * 2 + 0] = fabsf(a.t[L.b_idx][row]) + other * INPUT_BOUND;
+            rs[((size_t)li * 256 + row) * 2 + 1] = hid;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(PackArgs a, const float* rs, float* scales) {
     __shared__ float red[256];
     __shared__ float bound[MAX_LAYERS];
     for (int li = 0; li < a.net.n_layers; ++li) {
         const LayerDesc& L = a.net.layer[li];
         const float bin = L.src_layer >= 0 ? bound[L.src_layer] : 0.0f;
         float m = 0.0f;
-        for (int row = threadIdx.x; row < L.out_dim; row += 256) {
-            const float* W = a.t[L.w_idx] + (size_t)row * L.in_dim;
-            float sum = fabsf(a.t[L.b_idx][row]);
-            for (int col = 0; col < L.in_dim; ++col) {
-                const bool hid = col >= L.hid_col && col < L.hid_col + L.hid_feats;
-                sum += fabsf(W[col]) * (hid ? bin : INPUT_BOUND);
-            }
-            m = fmaxf(m, sum);
+        if ((int)threadIdx.x < L.out_dim) {
+            const float* r = rs + ((size_t)li * 256 + threadIdx.x) * 2;
+            m = r[0] + r[1] * bin;
         }
         red[threadIdx.x] = m;
         __syncthreads();
@@ -444,7 +377,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
         const float* scales = reinterpret_cast<const float*>(a.out + (size_t)a.padded_frags * FRAG_BYTES +
                                                              (size_t)a.net.n_bias_tiles * BIAS_TILE_BYTES);
         float s_out = 1.0f, s_hid = 1.0f;
-        if (a.bf16) {
+        if (a.bf16 && a.with_scales) {
             const bool head_row = L.kind == LK_FEATURE_ALPHA && tile == 8;
             s_out = (L.scaled_out && !head_row) ? scales[li] : 1.0f;
             s_hid = L.src_layer >= 0 ? scales[L.src_layer] : 1.0f;
@@ -457,7 +390,12 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
                 const int npe = L.has_pe ? 4 : 0, nh = L.hid_feats / 16;
                 if (g < npe) { const int ft = pe_slot_feature(h, 8 * g + j); col = ft < 0 ? -1 : L.pe_col + ft; }
                 else if (g < npe + nh) { const int hs = g - npe; col = L.hid_col + 16 * hs + 8 * (j >> 2) + 4 * h + (j & 3); }
-                else { const int ft = view_slot_feature(h, 8 * (g - npe - nh) + j); col = ft < 0 ? -1 : L.view_col + ft; }
+                else if (g < npe + nh + (L.has_view ? 2 : 0)) {
+                    const int ft = view_slot_feature(h, 8 * (g - npe - nh) + j); col = ft < 0 ? -1 : L.view_col + ft;
+                } else {
+                    col = 8 * (j >> 2) + 4 * h + (j & 3);
+                    extra = true;
+                }
             } else {
                 const int npe = L.has_pe ? 8 : 0, nh = L.hid_feats / 8;
                 if (g < npe) { const int ft = pe_slot_feature(h, 4 * g + j); col = ft < 0 ? -1 : L.pe_col + ft; }
@@ -483,7 +421,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
                 continue;
             }
             vals[j] = (W && col >= 0) ? W[(size_t)row * L.in_dim + col] : 0.0f;
-            if (a.bf16) {
+            if (a.bf16 && a.with_scales) {
                 const int npe = L.has_pe ? 4 : 0, nh = L.hid_feats / 16;
                 vals[j] *= (g >= npe && g < npe + nh) ? s_out / s_hid : s_out;
             }
@@ -510,7 +448,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
         int row;
         const float* Bp = pack_row(a, a.net.layer[li], t, rr, true, row);
         float v = Bp ? Bp[row] : 0.0f;
-        if (a.bf16) {
+        if (a.bf16 && a.with_scales) {
             const LayerDesc& L = a.net.layer[li];
             const float* scales = reinterpret_cast<const float*>(a.out + (size_t)a.padded_frags * FRAG_BYTES +
                                                                  (size_t)a.net.n_bias_tiles * BIAS_TILE_BYTES);
@@ -556,14 +494,27 @@ __global__ void selftest_kernel(int* bad) {
 }
 
 int launch_pack(const PackArgs& a, hipStream_t stream) {
-    if (a.bf16) {   // output scales first: the pack kernel reads them from behind the bias block
+    if (a.bf16 && a.with_scales) {   // output scales first: the pack kernel reads them from behind the bias block
         float* scales = reinterpret_cast<float*>(a.out + (size_t)a.padded_frags * FRAG_BYTES +
                                                  (size_t)a.net.n_bias_tiles * BIAS_TILE_BYTES);
-        hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(256), 0, stream, a, scales);
+        float* rs = scales + SCALE_BYTES / 4;
+        hipLaunchKernelGGL(rowsum_kernel, dim3(a.net.n_layers, 8), dim3(256), 0, stream, a, rs);
+        NERF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(256), 0, stream, a, rs, scales);
         NERF_LAUNCH_CHECK();
     }
     const int threads = a.padded_frags * 64 + a.net.n_bias_tiles * 32;
     hipLaunchKernelGGL(pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, a);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+}
+
+int launch_mlp_bf16_train(const MlpArgs& a, bool use_viewdirs, int output_ch, hipStream_t st) {
+    const long long n_tiles = (a.M + 255) / 256;
+    const dim3 grid((unsigned)(n_tiles < cu_count() ? n_tiles : cu_count())), block(MLP_THREADS);
+    if (use_viewdirs) hipLaunchKernelGGL((mlp_bf16_kernel<true, 4, true>), grid, block, 0, st, a);
+    else if (output_ch == 4) hipLaunchKernelGGL((mlp_bf16_kernel<false, 4, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((mlp_bf16_kernel<false, 5, true>), grid, block, 0, st, a);
     NERF_LAUNCH_CHECK();
     return NERF_OK;
 }
@@ -602,7 +553,8 @@ static int frag_total(int precision, int use_viewdirs) {
 extern "C" size_t nerf_mlp_packed_bytes(int precision, int use_viewdirs) {
     if (precision != NERF_PREC_BF16 && precision != NERF_PREC_F32) return 0;
     return (size_t)frag_total(precision, use_viewdirs) * FRAG_BYTES +
-           (size_t)(use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD) * BIAS_TILE_BYTES + SCALE_BYTES;
+           (size_t)(use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD) * BIAS_TILE_BYTES + SCALE_BYTES +
+           (precision == NERF_PREC_BF16 ? ROWSUM_BYTES : 0);
 }
 
 extern "C" int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs, int output_ch, int precision,
@@ -614,6 +566,7 @@ extern "C" int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs,
     PackArgs a;
     a.net = make_net_desc(use_viewdirs != 0, output_ch);
     a.bf16 = precision == NERF_PREC_BF16;
+    a.with_scales = a.bf16;
     a.total_frags = total_frags(a.net, a.bf16);
     NERF_REQUIRE(a.total_frags == frag_total(precision, use_viewdirs) &&
                      a.net.n_bias_tiles == (use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD),
@@ -655,14 +608,15 @@ extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewd
     a.n_stages = frag_total(precision, use_viewdirs) / STAGE_FRAGS;
     a.n_bias_tiles = use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD;
     a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
+    a.tape = nullptr;
     const int per_tile = precision == NERF_PREC_BF16 ? 256 : 128;
     const long long n_tiles = (M + per_tile - 1) / per_tile;
     const int grid = (int)(n_tiles < cu_count() ? n_tiles : cu_count());
     hipStream_t st = as_stream(stream);
     if (precision == NERF_PREC_BF16) {
-        if (use_viewdirs) hipLaunchKernelGGL((mlp_bf16_kernel<true, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
-        else if (output_ch == 4) hipLaunchKernelGGL((mlp_bf16_kernel<false, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
-        else hipLaunchKernelGGL((mlp_bf16_kernel<false, 5>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+        if (use_viewdirs) hipLaunchKernelGGL((mlp_bf16_kernel<true, 4, false>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+        else if (output_ch == 4) hipLaunchKernelGGL((mlp_bf16_kernel<false, 4, false>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((mlp_bf16_kernel<false, 5, false>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
     } else {
         if (use_viewdirs) hipLaunchKernelGGL((mlp_f32_kernel<true, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
         else if (output_ch == 4) hipLaunchKernelGGL((mlp_f32_kernel<false, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);

@@ -51,6 +51,7 @@ struct MlpArgs {
     int R, S, ray_cols;
     long long M;                   // samples
     float* out;
+    unsigned char* tape;           // bf16 training forward only (train_bf16.h)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -323,6 +324,7 @@ struct PackArgs {
     NetDesc net;
     const float* t[24];
     int bf16;
+    int with_scales;      // bf16 forward stream: output scales are computed and folded into weights and biases
     int total_frags;      // fragments the descriptor defines
     int padded_frags;     // >= total_frags; the tail is zero-filled (keeps the stream stage-aligned)
     unsigned char* out;

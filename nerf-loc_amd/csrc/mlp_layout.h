@@ -67,7 +67,7 @@ struct NetDesc {
 };
 
 __host__ __device__ constexpr int ksteps_bf16(const LayerDesc& L) {
-    return (L.has_pe ? 4 : 0) + L.hid_feats / 16 + (L.has_view ? 2 : 0);
+    return (L.has_pe ? 4 : 0) + L.hid_feats / 16 + (L.has_view ? 2 : 0) + L.extra_frags;
 }
 __host__ __device__ constexpr int frags_f32(const LayerDesc& L) {
     return (L.has_pe ? 8 : 0) + L.hid_feats / 8 + (L.has_view ? 4 : 0) + L.extra_frags;
@@ -130,12 +130,13 @@ inline NetDesc make_net_desc(bool use_viewdirs, int output_ch) {
     return n;
 }
 
-// Input-gradient chain, float32 only.  Layers in execution order, with view directions:
+// Input-gradient chain.  Layers in execution order, with view directions:
 //   rgb_linear^T (3 -> 128), views_linears.0^T restricted to the feature columns (128 -> 256),
 //   feature_linear^T plus alpha_linear^T (256 + 1 -> 256), then pts_linears 7..1 transposed
 //   (layer 5: only the 256 hidden columns, the encoded-input columns have no leaves behind them);
-// without: output_linear^T (output_ch -> 256), then pts_linears 7..1.
-inline NetDesc make_backward_desc(bool use_viewdirs, int output_ch) {
+// without: output_linear^T (output_ch -> 256), then pts_linears 7..1.  The smallest k part is one fragment: 8 input
+// features in float32, 16 in bf16.
+inline NetDesc make_backward_desc(bool use_viewdirs, int output_ch, bool bf16 = false) {
     NetDesc n{};
     int li = 0;
     auto add = [&](int tiles, int out_dim, int kfeats, int w_idx, int in_dim, int row_off, int k_limit) -> LayerDesc& {
@@ -147,12 +148,12 @@ inline NetDesc make_backward_desc(bool use_viewdirs, int output_ch) {
         return n.layer[li++];
     };
     if (use_viewdirs) {
-        add(4, 128, 8, 22, 128, 0, 3);                 // d(view hidden) = rgb_linear.weight^T d(rgb)
+        add(4, 128, bf16 ? 16 : 8, 22, 128, 0, 3);     // d(view hidden) = rgb_linear.weight^T d(rgb)
         add(8, 256, 128, 16, 283, 0, 128);             // d(feature) = views_linears.0.weight[:, :256]^T d(view hidden)
         LayerDesc& fa = add(8, 256, 256, 18, 256, 0, 256);   // d(h8) = feature^T d(feature) + alpha^T d(sigma)
         fa.extra_frags = 1; fa.w2_idx = 20; fa.in_dim2 = 256; fa.k_limit2 = 1;
     } else {
-        add(8, 256, 8, 18, 256, 0, output_ch);         // d(h8) = output_linear.weight^T d(raw)
+        add(8, 256, bf16 ? 16 : 8, 18, 256, 0, output_ch);   // d(h8) = output_linear.weight^T d(raw)
     }
     for (int i = 7; i >= 1; --i) add(8, 256, 256, 2 * i, i == 5 ? 319 : 256, i == 5 ? 63 : 0, 256);
     n.n_layers = li;
@@ -161,6 +162,8 @@ inline NetDesc make_backward_desc(bool use_viewdirs, int output_ch) {
 }
 constexpr int FRAGS_BWD_F32_VD = 4 * 1 + 8 * 16 + 8 * 33 + 7 * 8 * 32;               // 2188
 constexpr int FRAGS_BWD_F32_NOVD = 8 * 1 + 7 * 8 * 32;                                // 1800
+constexpr int FRAGS_BWD_BF16_VD = 4 * 1 + 8 * 8 + 8 * 17 + 7 * 8 * 16;               // 1100
+constexpr int FRAGS_BWD_BF16_NOVD = 8 * 1 + 7 * 8 * 16;                               // 904
 constexpr int pad_to_stage(int f) { return (f + STAGE_FRAGS - 1) / STAGE_FRAGS * STAGE_FRAGS; }
 
 inline int total_frags(const NetDesc& n, int prec_bf16) {
@@ -177,7 +180,8 @@ constexpr int FRAGS_F32_NOVD = 8 * 8 + 4 * 8 * 32 + 8 * 40 + 2 * 8 * 32 + 32;   
 constexpr int BIAS_TILES_VD = 64 + 9 + 4 + 1;    // 78
 constexpr int BIAS_TILES_NOVD = 64 + 1;          // 65
 constexpr int BIAS_TILE_BYTES = 32 * 4;
-constexpr int SCALE_BYTES = 64;                  // MAX_LAYERS output scales behind the bias block (pack-time scratch)
+constexpr int SCALE_BYTES = 64;                  // MAX_LAYERS output scales behind the bias block
+constexpr int ROWSUM_BYTES = MAX_LAYERS * 256 * 2 * 4;   // behind the scales: pack-time scratch (per-row |W| sums)
 constexpr float INPUT_BOUND = 16777216.0f;       // |network input| assumed <= 2^24 when the scales are chosen
 
 static_assert(FRAGS_BF16_VD % STAGE_FRAGS == 0 && FRAGS_BF16_NOVD % STAGE_FRAGS == 0, "stage-aligned");

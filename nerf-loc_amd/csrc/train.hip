@@ -20,6 +20,7 @@
 // 2 KB/sample/layer of tape traffic (HBM-balanced at float32).
 #include <math.h>
 #include "mlp_device.h"
+#include "train_bf16.h"
 #include "wgrad.h"
 
 namespace nerf {
@@ -354,26 +355,40 @@ static int check_arch(const char* who, int use_viewdirs, int output_ch) {
 }
 static int bwd_frags(int use_viewdirs) { return use_viewdirs ? FRAGS_BWD_F32_VD : FRAGS_BWD_F32_NOVD; }
 
-extern "C" size_t nerf_train_tape_bytes(long long M, int use_viewdirs) {
-    return M < 0 ? 0 : (size_t)pad128(M) * tape_floats(use_viewdirs != 0) * sizeof(float);
+static bool known_precision(int p) { return p == NERF_PREC_F32 || p == NERF_PREC_BF16; }
+
+extern "C" size_t nerf_train_tape_bytes(long long M, int use_viewdirs, int precision) {
+    if (M < 0 || !known_precision(precision)) return 0;
+    if (precision == NERF_PREC_BF16) return tape16_bytes(M, use_viewdirs != 0);
+    return (size_t)pad128(M) * tape_floats(use_viewdirs != 0) * sizeof(float);
 }
-extern "C" size_t nerf_train_grad_tape_bytes(long long M, int use_viewdirs) {
-    return M < 0 ? 0 : (size_t)pad128(M) * gtape_floats(use_viewdirs != 0) * sizeof(float);
+extern "C" size_t nerf_train_grad_tape_bytes(long long M, int use_viewdirs, int precision) {
+    if (M < 0 || !known_precision(precision)) return 0;
+    if (precision == NERF_PREC_BF16) return gtape16_bytes(M, use_viewdirs != 0);
+    return (size_t)pad128(M) * gtape_floats(use_viewdirs != 0) * sizeof(float);
 }
 extern "C" size_t nerf_train_workspace_bytes(void) {
     return ((size_t)WG_MAX_PARTS * 256 * 256 + (size_t)WG_MAX_PARTS * 256) * sizeof(float);
 }
-extern "C" size_t nerf_mlp_backward_packed_bytes(int use_viewdirs) {
+extern "C" size_t nerf_mlp_backward_packed_bytes(int use_viewdirs, int precision) {
+    if (!known_precision(precision)) return 0;
+    if (precision == NERF_PREC_BF16)
+        return (size_t)pad_to_stage(use_viewdirs ? FRAGS_BWD_BF16_VD : FRAGS_BWD_BF16_NOVD) * FRAG_BYTES;
     return (size_t)pad_to_stage(bwd_frags(use_viewdirs)) * FRAG_BYTES;
 }
 
-extern "C" int nerf_mlp_pack_backward(const float* const* tensors_host, int use_viewdirs, int output_ch,
+extern "C" int nerf_mlp_pack_backward(const float* const* tensors_host, int use_viewdirs, int output_ch, int precision,
                                       void* packed_out, void* stream) {
     NERF_REQUIRE(tensors_host && packed_out, "nerf_mlp_pack_backward: null pointer");
+    NERF_REQUIRE(known_precision(precision), "nerf_mlp_pack_backward: unknown precision %d", precision);
     if (int rc = check_arch("nerf_mlp_pack_backward", use_viewdirs, output_ch)) return rc;
+    NERF_REQUIRE(((uintptr_t)packed_out & 15) == 0, "nerf_mlp_pack_backward: packed_out must be 16-byte aligned");
+    if (precision == NERF_PREC_BF16)
+        return pack_backward_bf16(tensors_host, use_viewdirs != 0, output_ch, packed_out, as_stream(stream));
     PackArgs a;
     a.net = make_backward_desc(use_viewdirs != 0, output_ch);
     a.bf16 = 0;
+    a.with_scales = 0;
     a.total_frags = total_frags(a.net, 0);
     a.padded_frags = pad_to_stage(bwd_frags(use_viewdirs));
     NERF_REQUIRE(a.total_frags == bwd_frags(use_viewdirs), "nerf_mlp_pack_backward: internal layout mismatch");
@@ -387,10 +402,12 @@ extern "C" int nerf_mlp_pack_backward(const float* const* tensors_host, int use_
     return launch_pack(a, as_stream(stream));
 }
 
-extern "C" int nerf_mlp_forward_train(const void* packed, int use_viewdirs, int output_ch, int input_mode,
+extern "C" int nerf_mlp_forward_train(const void* packed, int precision, int use_viewdirs, int output_ch, int input_mode,
                                       const float* in0, const float* in1, int R, int S, int ray_cols, float* raw_out,
-                                      float* tape, void* stream) {
+                                      void* tape_v, void* stream) {
+    float* tape = static_cast<float*>(tape_v);
     NERF_REQUIRE(packed && (R == 0 || (in0 && raw_out && tape)), "nerf_mlp_forward_train: null pointer");
+    NERF_REQUIRE(known_precision(precision), "nerf_mlp_forward_train: unknown precision %d", precision);
     NERF_REQUIRE(R >= 0 && S >= 1, "nerf_mlp_forward_train: bad shape R=%d S=%d", R, S);
     if (int rc = check_arch("nerf_mlp_forward_train", use_viewdirs, output_ch)) return rc;
     switch (input_mode) {
@@ -413,10 +430,16 @@ extern "C" int nerf_mlp_forward_train(const void* packed, int use_viewdirs, int 
     a.n_stages = (use_viewdirs ? FRAGS_F32_VD : FRAGS_F32_NOVD) / STAGE_FRAGS;
     a.n_bias_tiles = use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD;
     a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
+    a.tape = nullptr;
+    hipStream_t st = as_stream(stream);
+    if (precision == NERF_PREC_BF16) {
+        a.n_stages = (use_viewdirs ? FRAGS_BF16_VD : FRAGS_BF16_NOVD) / STAGE_FRAGS;
+        a.tape = static_cast<unsigned char*>(tape_v);
+        return launch_mlp_bf16_train(a, use_viewdirs != 0, output_ch, st);
+    }
     const long long n_tiles = (M + 127) / 128;
     const dim3 grid((unsigned)(n_tiles < cu_count() ? n_tiles : cu_count())), block(MLP_THREADS);
     const TapePtrs tp = tape_ptrs(tape, M, use_viewdirs != 0);
-    hipStream_t st = as_stream(stream);
     if (use_viewdirs) hipLaunchKernelGGL((mlp_f32_train_kernel<true, 4>), grid, block, 0, st, a, tp);
     else if (output_ch == 4) hipLaunchKernelGGL((mlp_f32_train_kernel<false, 4>), grid, block, 0, st, a, tp);
     else hipLaunchKernelGGL((mlp_f32_train_kernel<false, 5>), grid, block, 0, st, a, tp);
@@ -424,10 +447,14 @@ extern "C" int nerf_mlp_forward_train(const void* packed, int use_viewdirs, int 
     return NERF_OK;
 }
 
-extern "C" int nerf_mlp_backward(const void* packed_bwd, int use_viewdirs, int output_ch, const float* d_raw, long long M,
-                                 const float* tape, float* grad_tape, float* workspace, size_t workspace_bytes,
-                                 float* const* grads_host, void* stream) {
+extern "C" int nerf_mlp_backward(const void* packed_bwd, const void* packed_fwd, int precision, int use_viewdirs,
+                                 int output_ch, const float* d_raw, long long M, const void* tape_v, void* grad_tape_v,
+                                 float* workspace, size_t workspace_bytes, float* const* grads_host, void* stream) {
+    const float* tape = static_cast<const float*>(tape_v);
+    float* grad_tape = static_cast<float*>(grad_tape_v);
     NERF_REQUIRE(packed_bwd && d_raw && tape && grad_tape && workspace && grads_host, "nerf_mlp_backward: null pointer");
+    NERF_REQUIRE(known_precision(precision), "nerf_mlp_backward: unknown precision %d", precision);
+    NERF_REQUIRE(precision != NERF_PREC_BF16 || packed_fwd, "nerf_mlp_backward: the bf16 backward needs the forward stream");
     if (int rc = check_arch("nerf_mlp_backward", use_viewdirs, output_ch)) return rc;
     NERF_REQUIRE(workspace_bytes >= nerf_train_workspace_bytes(), "nerf_mlp_backward: workspace of %zu bytes, %zu needed",
                  workspace_bytes, nerf_train_workspace_bytes());
@@ -438,6 +465,9 @@ extern "C" int nerf_mlp_backward(const void* packed_bwd, int use_viewdirs, int o
     for (int i = 0; i < n_t; ++i)
         if (use_viewdirs || (i != 16 && i != 17)) NERF_REQUIRE(grads_host[i], "nerf_mlp_backward: gradient tensor %d is null", i);
     hipStream_t st = as_stream(stream);
+    if (precision == NERF_PREC_BF16)
+        return backward_bf16(packed_bwd, packed_fwd, use_viewdirs != 0, output_ch, d_raw, M, tape_v, grad_tape_v, workspace,
+                             grads_host, st);
     const TapePtrs tp = tape_ptrs(const_cast<float*>(tape), M, use_viewdirs != 0);
     const GTapePtrs gt = gtape_ptrs(grad_tape, M, use_viewdirs != 0);
     DgradArgs d;

@@ -14,4 +14,17 @@ int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K,
 int launch_wgrad_small(const float* d_raw, int ldr, int c0, int N, const float* X, int K, long long M, float* ws,
                        float* dW, float* db, hipStream_t st);
 
+// Second phase alone, for partial tiles [parts][256][pcol] in ws (bias partials behind them as in launch_wgrad):
+// maps 3 / 4 are the encoded-point / encoded-view columns in the bf16 operand order; *x_scale (device pointer or
+// null) is a power of two the inputs were stored multiplied by.
+int launch_wgrad_reduce(const float* ws, int parts, int pcol, int n_rows, int k_emit, float* dW, int ld, int col_off,
+                        int map, const float* x_scale, float* db, hipStream_t st);
+
+// bf16 training (train_bf16.hip)
+size_t tape16_bytes(long long M, bool vd);
+size_t gtape16_bytes(long long M, bool vd);
+int pack_backward_bf16(const float* const* tensors_host, bool vd, int output_ch, void* packed_out, hipStream_t st);
+int backward_bf16(const void* packed_bwd, const void* packed_fwd, bool vd, int output_ch, const float* d_raw, long long M,
+                  const void* tape, void* grad_tape, float* ws, float* const* grads_host, hipStream_t st);
+
 }  // namespace nerf

@@ -131,21 +131,31 @@ __global__ void wgrad_small_kernel(WsmallArgs a) {
 }
 
 // dst[row * ld + col_off + map(col)] = sum over parts, in part order.  map: 0 identity, 1 encoded-point
-// k-slot -> reference column, 2 encoded-view k-slot -> reference column (slots without a feature are dropped).
+// k-slot -> reference column, 2 encoded-view k-slot -> reference column (slots without a feature are dropped);
+// 3, 4: the same for the bf16 operand order, where column 16 s + f of the partial tile is element
+// j = 4 (f >> 3) + (f & 3) of lane half (f >> 2) & 1 in k-step s, i.e. slot 8 s + j of that half (mlp_layout.h).
+// x_scale (device, may be null): the inputs were stored multiplied by *x_scale, a power of two; undone here.
 struct ReduceArgs {
     const float* part; int n_parts; int prow; int pcol;   // [n_parts][prow][pcol]
     int N, K;                                             // rows / columns to emit
     float* dst; int ld; int col_off; int map;
+    const float* x_scale;
+    const float* bpart; float* db;                        // optional: block row N adds [n_parts][256] into db[N]
 };
 __global__ void wgrad_reduce_kernel(ReduceArgs a) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
-    if (col >= a.K || row >= a.N) return;
+    const bool bias_row = row == a.N && a.db;
+    if (bias_row ? col >= a.N : (col >= a.K || row >= a.N)) return;
     int dc = col;
     if (a.map == 1) dc = pe_slot_feature(col >> 5, col & 31);
     else if (a.map == 2) dc = view_slot_feature(col >> 4, col & 15);
-    if (dc < 0) return;
-    const float* p = a.part + (size_t)row * a.pcol + col;
-    const size_t stride = (size_t)a.prow * a.pcol;
+    else if (a.map >= 3) {
+        const int f = col & 15, hh = (f >> 2) & 1, q = 8 * (col >> 4) + 4 * (f >> 3) + (f & 3);
+        dc = a.map == 3 ? pe_slot_feature(hh, q) : view_slot_feature(hh, q);
+    }
+    if (dc < 0 && !bias_row) return;
+    const float* p = bias_row ? a.bpart + col : a.part + (size_t)row * a.pcol + col;
+    const size_t stride = bias_row ? 256 : (size_t)a.prow * a.pcol;
     // eight interleaved chains keep eight loads in flight; the order of additions is fixed
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int i = 0;
@@ -154,7 +164,20 @@ __global__ void wgrad_reduce_kernel(ReduceArgs a) {
         for (int j = 0; j < 8; ++j) s[j] += p[(size_t)(i + j) * stride];
     }
     for (int j = 0; i < a.n_parts; ++i, ++j) s[j] += p[(size_t)i * stride];
-    a.dst[(size_t)row * a.ld + a.col_off + dc] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    float sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    if (bias_row) { a.db[col] = sum; return; }
+    if (a.x_scale) sum *= 1.0f / *a.x_scale;
+    a.dst[(size_t)row * a.ld + a.col_off + dc] = sum;
+}
+
+int launch_wgrad_reduce(const float* ws, int parts, int pcol, int n_rows, int k_emit, float* dW, int ld, int col_off,
+                        int map, const float* x_scale, float* db, hipStream_t st) {
+    ReduceArgs r{ws, parts, 256, pcol, n_rows, k_emit, dW, ld, col_off, map, x_scale,
+                 ws + (size_t)WG_MAX_PARTS * 256 * 256, db};
+    const int cols = k_emit > n_rows ? k_emit : n_rows;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cols + 63) / 64, n_rows + (db ? 1 : 0)), dim3(64), 0, st, r);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
 }
 
 int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K, long long M,
@@ -179,11 +202,11 @@ int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K,
         default: hipLaunchKernelGGL(wgrad_kernel<8>, grid, block, 0, st, a); break;
     }
     NERF_LAUNCH_CHECK();
-    ReduceArgs r{ws, (int)parts, 256, 32 * ctp, N, map == 0 ? K : 32 * ct, dW, ld, col_off, map};
+    ReduceArgs r{ws, (int)parts, 256, 32 * ctp, N, map == 0 ? K : 32 * ct, dW, ld, col_off, map, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r.K + 63) / 64, N), dim3(64), 0, st, r);
     NERF_LAUNCH_CHECK();
     if (db) {
-        ReduceArgs rb{a.bpart, (int)parts, 1, 256, 1, N, db, N, 0, 0};
+        ReduceArgs rb{a.bpart, (int)parts, 1, 256, 1, N, db, N, 0, 0, nullptr, nullptr, nullptr};
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N + 63) / 64, 1), dim3(64), 0, st, rb);
         NERF_LAUNCH_CHECK();
     }
@@ -200,10 +223,10 @@ int launch_wgrad_small(const float* d_raw, int ldr, int c0, int N, const float* 
     WsmallArgs a{d_raw, ldr, c0, N, X, K, M, chunk, ws, ws + (size_t)1024 * 8 * 256};
     hipLaunchKernelGGL(wgrad_small_kernel, dim3((unsigned)parts), dim3(K), 0, st, a);
     NERF_LAUNCH_CHECK();
-    ReduceArgs r{ws, (int)parts, 8, K, N, K, dW, K, 0, 0};
+    ReduceArgs r{ws, (int)parts, 8, K, N, K, dW, K, 0, 0, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K + 63) / 64, N), dim3(64), 0, st, r);
     NERF_LAUNCH_CHECK();
-    ReduceArgs rb{a.bpart, (int)parts, 1, 8, 1, N, db, N, 0, 0};
+    ReduceArgs rb{a.bpart, (int)parts, 1, 8, 1, N, db, N, 0, 0, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1, 1), dim3(64), 0, st, rb);
     NERF_LAUNCH_CHECK();
     return NERF_OK;

@@ -100,6 +100,7 @@ class NeRF(nn.Module):
         self.use_viewdirs = use_viewdirs
         self.output_ch = output_ch
         self.precision = None          # None: follow set_default_precision()
+        self.train_precision = None    # None: follow train.set_train_precision() (float32 unless changed)
         self._pack_cache = {}
 
         layers = [nn.Linear(input_ch, W)]

@@ -48,18 +48,18 @@ _SIGNATURES = {
     "nerf_raw2outputs_backward": (ctypes.c_int, [_c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int,
                                                  _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p,
                                                  _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
-    "nerf_train_tape_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int]),
-    "nerf_train_grad_tape_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int]),
+    "nerf_train_tape_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
+    "nerf_train_grad_tape_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
     "nerf_train_workspace_bytes": (ctypes.c_size_t, []),
-    "nerf_mlp_forward_train": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p,
-                                              _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p,
-                                              _c_float_p, ctypes.c_void_p]),
-    "nerf_mlp_backward_packed_bytes": (ctypes.c_size_t, [ctypes.c_int]),
-    "nerf_mlp_pack_backward": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
+    "nerf_mlp_forward_train": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              _c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "nerf_mlp_backward_packed_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "nerf_mlp_pack_backward": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_void_p]),
-    "nerf_mlp_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_longlong,
-                                         _c_float_p, _c_float_p, _c_float_p, ctypes.c_size_t,
-                                         ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    "nerf_mlp_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         _c_float_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, _c_float_p,
+                                         ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "nerf_adam_step": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.POINTER(ctypes.c_longlong), ctypes.c_longlong, ctypes.c_float,
@@ -318,44 +318,51 @@ def raw2outputs_backward(raw, z, d, d_stride, noise, white_bkgd, g_rgb=None, g_d
     return d_raw
 
 
-def mlp_pack_backward(tensors, use_viewdirs, output_ch):
+def mlp_pack_backward(tensors, use_viewdirs, output_ch, precision="fp32"):
     """tensors: state_dict-ordered list (24 with view directions, 20 without; unused entries may be None)."""
+    prec = PRECISIONS[precision]
     dev = next(t for t in tensors if t is not None).device
     keep = [None if t is None else _f32(t.detach(), "weight %d" % i, dev) for i, t in enumerate(tensors)]
     arr = (ctypes.c_void_p * len(keep))(*[None if t is None else t.data_ptr() for t in keep])
-    packed = torch.empty((lib().nerf_mlp_backward_packed_bytes(int(bool(use_viewdirs))),), dtype=torch.uint8, device=dev)
+    packed = torch.empty((lib().nerf_mlp_backward_packed_bytes(int(bool(use_viewdirs)), prec),), dtype=torch.uint8,
+                         device=dev)
     with torch.cuda.device(dev):
-        _check(lib().nerf_mlp_pack_backward(arr, int(bool(use_viewdirs)), int(output_ch),
+        _check(lib().nerf_mlp_pack_backward(arr, int(bool(use_viewdirs)), int(output_ch), prec,
                                             ctypes.c_void_p(packed.data_ptr()), _stream(packed)), "nerf_mlp_pack_backward")
     return packed
 
 
-def mlp_forward_train(packed, use_viewdirs, output_ch, mode, in0, in1, R, S, ray_cols=0):
-    """float32 forward that keeps its activations: returns (raw [R*S, output_ch], tape)."""
+def mlp_forward_train(packed, use_viewdirs, output_ch, mode, in0, in1, R, S, ray_cols=0, precision="fp32"):
+    """Forward that keeps its activations: returns (raw [R*S, output_ch], tape).  `packed` must come from mlp_pack
+    with the same precision."""
+    prec = PRECISIONS[precision]
     in0 = _f32(in0, "mlp input")
     in1 = _f32(in1, "mlp second input", in0.device) if in1 is not None else None
     M = R * S
     vd = int(bool(use_viewdirs))
     out = torch.empty((M, output_ch), dtype=torch.float32, device=in0.device)
-    tape = torch.empty((lib().nerf_train_tape_bytes(M, vd) // 4,), dtype=torch.float32, device=in0.device)
+    tape = torch.empty((lib().nerf_train_tape_bytes(M, vd, prec) // 4,), dtype=torch.float32, device=in0.device)
     with torch.cuda.device(in0.device):
-        _check(lib().nerf_mlp_forward_train(ctypes.c_void_p(packed.data_ptr()), vd, int(output_ch), mode, _ptr(in0),
-                                            _ptr(in1), int(R), int(S), int(ray_cols), _ptr(out), _ptr(tape),
-                                            _stream(out)), "nerf_mlp_forward_train")
+        _check(lib().nerf_mlp_forward_train(ctypes.c_void_p(packed.data_ptr()), prec, vd, int(output_ch), mode, _ptr(in0),
+                                            _ptr(in1), int(R), int(S), int(ray_cols), _ptr(out),
+                                            ctypes.c_void_p(tape.data_ptr()), _stream(out)), "nerf_mlp_forward_train")
     return out, tape
 
 
 _WORKSPACE = {}
 
 
-def mlp_backward(packed_bwd, use_viewdirs, output_ch, d_raw, tape, shapes):
+def mlp_backward(packed_bwd, use_viewdirs, output_ch, d_raw, tape, shapes, precision="fp32", packed_fwd=None):
     """Gradients of the parameter tensors: list in state_dict order shaped like `shapes` (None entries are
-    skipped and come back as None)."""
+    skipped and come back as None).  bf16: packed_fwd is the forward stream the tape was made with."""
+    prec = PRECISIONS[precision]
+    if precision == "bf16" and packed_fwd is None:
+        raise ValueError("mlp_backward: the bf16 backward needs packed_fwd")
     d_raw = _f32(d_raw, "d_raw")
     dev = d_raw.device
     M = d_raw.numel() // output_ch
     vd = int(bool(use_viewdirs))
-    gtape = torch.empty((lib().nerf_train_grad_tape_bytes(M, vd) // 4,), dtype=torch.float32, device=dev)
+    gtape = torch.empty((lib().nerf_train_grad_tape_bytes(M, vd, prec) // 4,), dtype=torch.float32, device=dev)
     ws = _WORKSPACE.get(str(dev))
     if ws is None:
         ws = _WORKSPACE[str(dev)] = torch.empty((lib().nerf_train_workspace_bytes() // 4,), dtype=torch.float32,
@@ -363,9 +370,11 @@ def mlp_backward(packed_bwd, use_viewdirs, output_ch, d_raw, tape, shapes):
     grads = [None if s is None else torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
     arr = (ctypes.c_void_p * len(grads))(*[None if g is None else g.data_ptr() for g in grads])
     with torch.cuda.device(dev):
-        _check(lib().nerf_mlp_backward(ctypes.c_void_p(packed_bwd.data_ptr()), vd, int(output_ch), _ptr(d_raw), M,
-                                       _ptr(tape), _ptr(gtape), _ptr(ws), ws.numel() * 4, arr, _stream(d_raw)),
-               "nerf_mlp_backward")
+        _check(lib().nerf_mlp_backward(ctypes.c_void_p(packed_bwd.data_ptr()),
+                                       ctypes.c_void_p(packed_fwd.data_ptr()) if packed_fwd is not None else None,
+                                       prec, vd, int(output_ch), _ptr(d_raw), M, ctypes.c_void_p(tape.data_ptr()),
+                                       ctypes.c_void_p(gtape.data_ptr()), _ptr(ws), ws.numel() * 4, arr,
+                                       _stream(d_raw)), "nerf_mlp_backward")
     return grads
 
 

@@ -10,8 +10,11 @@ torch.autograd.Function nodes wrap hand-written HIP kernels:
                 sample positions and view directions have no leaves behind them)
   _CompositeFn  raw2outputs: closed-form backward of the alpha compositing
 
-Training always computes in float32 (like the reference), whatever the
-``precision`` attribute says about inference.  The architecture is the one the
+Training computes in float32 (like the reference) unless bf16 is asked for
+explicitly (set_train_precision("bf16") or a model's ``train_precision``
+attribute): bf16 MFMA operands with float32 accumulation, parameters and
+gradients stay float32.  The inference ``precision`` attribute plays no part.
+The architecture is the one the
 inference kernels implement (D=8, W=256, skips=[4], with view directions or
 without and output_ch 4 / 5); others raise NotImplementedError.  Nothing here
 falls back to autograd over torch ops.
@@ -29,6 +32,23 @@ _PARAM_ORDER = {True: _TRUNK + ["views_linears.0.weight", "views_linears.0.bias"
                 False: _TRUNK + [None, None, "output_linear.weight", "output_linear.bias"]}
 
 
+_TRAIN_PRECISION = ["fp32"]
+
+
+def set_train_precision(name):
+    """'fp32' (default: what the reference computes) or 'bf16' for networks without their own ``train_precision``."""
+    if name not in ("fp32", "bf16"):
+        raise ValueError("unknown training precision %r" % (name,))
+    _TRAIN_PRECISION[0] = name
+
+
+def train_precision_of(model):
+    name = getattr(model, "train_precision", None) or _TRAIN_PRECISION[0]
+    if name not in ("fp32", "bf16"):
+        raise ValueError("unknown training precision %r" % (name,))
+    return name
+
+
 def _params(model):
     """Parameters in the kernels' tensor order (None for unused slots)."""
     if not model.hip_supported():
@@ -38,15 +58,15 @@ def _params(model):
     return [None if k is None else named[k] for k in _PARAM_ORDER[bool(model.use_viewdirs)]]
 
 
-def _packed_backward(model, params):
+def _packed_backward(model, params, precision):
     """Transposed-weight stream for the input-gradient chain, cached per weight version."""
     key = (hip.WEIGHT_GENERATION[0],) + tuple((p.data_ptr(), p._version) for p in params if p is not None)
-    hit = model._pack_cache.get("bwd")
+    hit = model._pack_cache.get(("bwd", precision))
     if hit is not None and hit[0] == key:
         return hit[1]
     packed = hip.mlp_pack_backward([None if p is None else p.detach() for p in params], model.use_viewdirs,
-                                   model.out_channels)
-    model._pack_cache["bwd"] = (key, packed)
+                                   model.out_channels, precision)
+    model._pack_cache[("bwd", precision)] = (key, packed)
     return packed
 
 
@@ -59,17 +79,22 @@ class _NetworkFn(torch.autograd.Function):
         full = [None] * len(slots)
         for p, i in zip(params, [i for i, used in enumerate(slots) if used]):
             full[i] = p
-        packed = model.packed_weights(hip.PREC_F32)
-        raw, tape = hip.mlp_forward_train(packed, model.use_viewdirs, model.out_channels, mode, in0, in1, R, S, ray_cols)
+        prec = train_precision_of(model)
+        packed = model.packed_weights(hip.PRECISIONS[prec])
+        raw, tape = hip.mlp_forward_train(packed, model.use_viewdirs, model.out_channels, mode, in0, in1, R, S, ray_cols,
+                                          precision=prec)
         ctx.tape = tape
-        ctx.packed_bwd = _packed_backward(model, full)
+        ctx.prec = prec
+        ctx.packed_fwd = packed
+        ctx.packed_bwd = _packed_backward(model, full, prec)
         ctx.shapes = [None if p is None else tuple(p.shape) for p in full]
         ctx.arch = (model.use_viewdirs, model.out_channels)
         return raw
 
     @staticmethod
     def backward(ctx, g_raw):
-        grads = hip.mlp_backward(ctx.packed_bwd, ctx.arch[0], ctx.arch[1], g_raw.contiguous(), ctx.tape, ctx.shapes)
+        grads = hip.mlp_backward(ctx.packed_bwd, ctx.arch[0], ctx.arch[1], g_raw.contiguous(), ctx.tape, ctx.shapes,
+                                 precision=ctx.prec, packed_fwd=ctx.packed_fwd)
         ctx.tape = None
         return (None,) * 8 + tuple(g for g in grads if g is not None)
 

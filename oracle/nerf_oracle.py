@@ -386,36 +386,48 @@ def raw2outputs_backward(raw, z_vals, rays_d, noise=None, white_bkgd=False, g_rg
     return out
 
 
-def mlp_backward(sd, feat, d_raw, use_viewdirs=True):
+def bf16_round(x):
+    """Round float32 values to the nearest bfloat16 (ties to even), returned as float64."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32).astype(np.float64)
+
+
+def mlp_backward(sd, feat, d_raw, use_viewdirs=True, bf16=False):
     """Gradients of the parameter tensors for dL/draw = d_raw [N, C], float64 (C = 4 with view directions, else the
     rows of output_linear).  Returns {state_dict name: gradient}; the view branch is pinned by the reference's
-    autograd gradients (g8), the branch without view directions shares the trunk and has no reference fixture."""
+    autograd gradients (g8), the branch without view directions shares the trunk and has no reference fixture.
+
+    bf16=True restates the mixed-precision training kernels instead: every matrix-product operand (weights, layer
+    inputs, stored activations, gradients) is rounded to bfloat16, sums are exact, ReLU masks come from the rounded
+    activations.  No reference fixture exists for it (the reference trains in float32)."""
     f = np.float64
-    W = {k: v.astype(f) for k, v in sd.items()}
-    x = feat.astype(f)
+    q = bf16_round if bf16 else (lambda v: np.asarray(v, f))
+    W = {k: (q(v) if k.endswith("weight") else v.astype(f)) for k, v in sd.items()}
+    x = q(feat)
     pts, views = x[:, :63], x[:, 63:90]
-    ins, pre = [], []
+    ins, act = [], []
     h = pts
     for i in range(8):
         ins.append(h)
         a = h @ W["pts_linears.%d.weight" % i].T + W["pts_linears.%d.bias" % i]
-        pre.append(a)
-        h = np.maximum(a, 0)
+        hr = q(np.maximum(a, 0))
+        act.append(hr)
+        h = hr
         if i == 4:
             h = np.concatenate([pts, h], -1)
     h8 = h
     g = {}
-    d = d_raw.astype(f)
+    d = q(d_raw)
     if use_viewdirs:
-        feature = h8 @ W["feature_linear.weight"].T + W["feature_linear.bias"]
+        feature = q(h8 @ W["feature_linear.weight"].T + W["feature_linear.bias"])
         hv_in = np.concatenate([feature, views], -1)
-        hv_pre = hv_in @ W["views_linears.0.weight"].T + W["views_linears.0.bias"]
-        hv = np.maximum(hv_pre, 0)
+        hv = q(np.maximum(hv_in @ W["views_linears.0.weight"].T + W["views_linears.0.bias"], 0))
         d_rgb, d_sig = d[:, :3], d[:, 3:4]
         g["rgb_linear.weight"], g["rgb_linear.bias"] = d_rgb.T @ hv, d_rgb.sum(0)
-        d_hv = (d_rgb @ W["rgb_linear.weight"]) * (hv_pre > 0)
+        d_hv = q((d_rgb @ W["rgb_linear.weight"]) * (hv > 0))
         g["views_linears.0.weight"], g["views_linears.0.bias"] = d_hv.T @ hv_in, d_hv.sum(0)
-        d_feat = (d_hv @ W["views_linears.0.weight"])[:, :256]
+        d_feat = q((d_hv @ W["views_linears.0.weight"])[:, :256])
         g["feature_linear.weight"], g["feature_linear.bias"] = d_feat.T @ h8, d_feat.sum(0)
         g["alpha_linear.weight"], g["alpha_linear.bias"] = d_sig.T @ h8, d_sig.sum(0)
         dh = d_feat @ W["feature_linear.weight"] + d_sig @ W["alpha_linear.weight"]
@@ -423,7 +435,7 @@ def mlp_backward(sd, feat, d_raw, use_viewdirs=True):
         g["output_linear.weight"], g["output_linear.bias"] = d.T @ h8, d.sum(0)
         dh = d @ W["output_linear.weight"]
     for i in range(7, -1, -1):
-        dz = dh * (pre[i] > 0)
+        dz = q(dh * (act[i] > 0))
         g["pts_linears.%d.weight" % i], g["pts_linears.%d.bias" % i] = dz.T @ ins[i], dz.sum(0)
         dh = dz @ W["pts_linears.%d.weight" % i]
         if i == 5:

@@ -77,8 +77,9 @@ def test_packed_sizes_host_only():
     lib = hip.lib()
     frag, bias = 1024, 128
     scales = 64          # pack-time scratch behind the bias block
-    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 1) == 1184 * frag + 78 * bias + scales
-    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 0) == 976 * frag + 65 * bias + scales
+    rowsums = 11 * 256 * 2 * 4          # pack-time scratch of the bf16 stream
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 1) == 1184 * frag + 78 * bias + scales + rowsums
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 0) == 976 * frag + 65 * bias + scales + rowsums
     assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 1) == 2368 * frag + 78 * bias + scales
     assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 0) == 1952 * frag + 65 * bias + scales
 

@@ -1,0 +1,146 @@
+"""Decode the bf16 training tapes and compare every layer with a float32 torch evaluation (debug aid)."""
+import sys
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from nerf_loc_amd import hip, synth, train      # noqa: E402
+from nerf_loc_amd.helpers import NeRF            # noqa: E402
+from oracle import nerf_oracle as orc            # noqa: E402
+
+dev = torch.device("cuda:0")
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 77
+sd = synth.make_state_dict(70, "B")
+net = NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+net = net.to(dev)
+rs = np.random.RandomState(M)
+x = rs.uniform(-3, 3, size=(M, 3)).astype(np.float32)
+d = rs.normal(size=(M, 3)); d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+feat = torch.from_numpy(np.concatenate([orc.embed(x, 10), orc.embed(d, 4)], -1).astype(np.float32)).to(dev)
+d_raw = torch.from_numpy(rs.randn(M, 4).astype(np.float32)).to(dev)
+
+# float32 torch evaluation with every pre-activation kept
+W = {k: v.detach() for k, v in net.named_parameters()}
+pts, views = feat[:, :63], feat[:, 63:]
+z, h = [], pts
+for i in range(8):
+    zi = (h @ W["pts_linears.%d.weight" % i].T + W["pts_linears.%d.bias" % i]).requires_grad_(True); zi.retain_grad()
+    z.append(zi); h = torch.relu(zi)
+    if i == 4: h = torch.cat([pts, h], -1)
+zs = []
+h7 = h
+alpha = h7 @ W["alpha_linear.weight"].T + W["alpha_linear.bias"]
+f = (h7 @ W["feature_linear.weight"].T + W["feature_linear.bias"]); f.retain_grad()
+zv = (torch.cat([f, views], -1) @ W["views_linears.0.weight"].T + W["views_linears.0.bias"]); zv.retain_grad()
+hv = torch.relu(zv)
+rgb = hv @ W["rgb_linear.weight"].T + W["rgb_linear.bias"]
+out = torch.cat([rgb, alpha], -1)
+# leaves need grad for retain_grad to work: make the first input require grad
+pts.requires_grad_(False)
+for t in z + [f, zv]:
+    pass
+(out * d_raw).sum().backward() if out.requires_grad else None
+
+prec = "bf16"
+vd = 1
+packed = net.packed_weights(hip.PRECISIONS[prec])
+raw, tape = hip.mlp_forward_train(packed, True, 4, hip.IN_FEATURES, feat, None, M, 1, 0, precision=prec)
+params = train._params(net)
+pb = hip.mlp_pack_backward([p.detach() for p in params], True, 4, prec)
+lib = hip.lib()
+import ctypes
+gt = torch.zeros((lib.nerf_train_grad_tape_bytes(M, vd, 1) // 4,), dtype=torch.float32, device=dev)
+ws = torch.empty((lib.nerf_train_workspace_bytes() // 4,), dtype=torch.float32, device=dev)
+grads = [torch.zeros_like(p) for p in params]
+arr = (ctypes.c_void_p * 24)(*[g.data_ptr() for g in grads])
+rc = lib.nerf_mlp_backward(ctypes.c_void_p(pb.data_ptr()), ctypes.c_void_p(packed.data_ptr()), 1, 1, 4,
+                           ctypes.cast(d_raw.data_ptr(), ctypes.POINTER(ctypes.c_float)), M, ctypes.c_void_p(tape.data_ptr()),
+                           ctypes.c_void_p(gt.data_ptr()), ctypes.cast(ws.data_ptr(), ctypes.POINTER(ctypes.c_float)), ws.numel() * 4, arr, None)
+torch.cuda.synchronize()
+print("backward rc", rc, "out err", float((raw - out.detach()).abs().max()))
+
+
+def decode(buf, total, p0, n):
+    a = buf.cpu().numpy().view(np.uint16).reshape(-1, total, 2, 64, 8)[:, p0:p0 + n]     # [blk, s, ct, lane, j]
+    a = (a.astype(np.uint32) << 16).view(np.float32)
+    nb = a.shape[0]
+    res = np.zeros((nb * 64, 16 * n), np.float32)
+    for s in range(n):
+        for ct in range(2):
+            for hh in range(2):
+                for j in range(8):
+                    fidx = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)
+                    m = np.arange(nb)[:, None] * 64 + 32 * ct + np.arange(32)[None, :]
+                    res[m, fidx] = a[:, s, ct, hh * 32:(hh + 1) * 32, j]
+    return res
+
+
+def cmp(name, got, ref, scaled=False):
+    got = got[:M]
+    ref = ref.detach().cpu().numpy()
+    if scaled:
+        nz = np.abs(ref) > 1e-3 * np.abs(ref).max()
+        r = np.median(np.abs(got[nz]) / np.abs(ref[nz])) if nz.any() else 1.0
+        sc = 2.0 ** np.round(np.log2(max(r, 1e-30)))
+        got = got / sc
+    else:
+        sc = 1.0
+    err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+    print("%-10s scale %-10g rel max err %.3e   (|ref| max %.3e)" % (name, sc, err, np.abs(ref).max()))
+
+
+T = 158
+hs = [torch.relu(zi) for zi in z]
+for i in range(8):
+    cmp("h%d" % i, decode(tape, T, 6 + 16 * i, 16), hs[i], True)
+cmp("feat", decode(tape, T, 134, 16), f, True)
+cmp("hv", decode(tape, T, 150, 8), hv, True)
+G = 156
+cmp("dzv", decode(gt, G, 144, 8), zv.grad)
+cmp("dfeat", decode(gt, G, 128, 16), f.grad)
+for i in range(7, -1, -1):
+    cmp("dz%d" % i, decode(gt, G, 16 * i, 16), z[i].grad)
+names = [k for k in train._PARAM_ORDER[True]]
+named = dict(net.named_parameters())
+got = decode(gt, G, 144, 8)[:M]
+ref = zv.grad.cpu().numpy()
+np.set_printoptions(precision=4, suppress=True, linewidth=200)
+print("dzv sample 0 got:", got[0, :24])
+print("dzv sample 0 ref:", ref[0, :24])
+print("dzv sample 40 got:", got[40, :24])
+print("dzv sample 40 ref:", ref[40, :24])
+unm = (d_raw[:, :3] @ W["rgb_linear.weight"]).cpu().numpy()
+print("unmasked ref s0:", unm[0, :24])
+drgb = decode(gt, G, 152, 2)[:M]
+print("drgb tape s0:", drgb[0, :8], "d_raw:", d_raw[0].cpu().numpy())
+print("frac rows where got==0 & ref!=0:", np.mean((got == 0) & (ref != 0)), " got!=0 & ref==0:", np.mean((got != 0) & (ref == 0)))
+hvt = decode(tape, T, 150, 8)          # [Mpad, 128] stored activations
+gz = decode(gt, G, 144, 8)
+unm_full = np.zeros_like(gz); unm_full[:M] = unm
+valid = np.zeros(gz.shape, bool); valid[:64] = np.abs(unm_full[:64]) > 1e-3
+gm = gz != 0
+def score(mask):
+    return float(np.mean(gm[valid] == mask[valid]))
+base_mask = hvt > 0
+print("identity", score(base_mask))
+for sh in (32, 64, 96):
+    print("feature roll", sh, score(np.roll(base_mask, -sh, axis=1)), score(np.roll(base_mask, sh, axis=1)))
+print("half swap", score(base_mask[:, np.arange(128) ^ 16]))
+print("h swap (f^4)", score(base_mask[:, np.arange(128) ^ 4]))
+print("f^8", score(base_mask[:, np.arange(128) ^ 8]))
+idx = np.arange(gz.shape[0])
+print("ct swap", score(base_mask[idx ^ 32]))
+for k in (1, 2, 3):
+    print("qd roll", k, score(base_mask[:, (np.arange(128) & ~3) | ((np.arange(128) + k) & 3)]))
+f_idx = np.arange(128)[None, :].repeat(gz.shape[0], 0)
+s_idx = np.arange(gz.shape[0])[:, None].repeat(128, 1)
+for name, key in (("half", (f_idx >> 4) & 1), ("ct", (s_idx >> 5) & 1), ("hh", (f_idx >> 2) & 1), ("j>>2", (f_idx >> 3) & 1), ("e", f_idx & 3), ("tile", f_idx >> 5)):
+    for v in np.unique(key):
+        sel = valid & (key == v)
+        if sel.any():
+            print(name, v, "identity score %.3f" % float(np.mean(gm[sel] == base_mask[sel])))
+print("alpha bias got", grads[21].cpu().numpy(), "ref sum d_sigma", float(d_raw[:, 3].sum()), "bf16-rounded", float(d_raw[:, 3].bfloat16().float().sum()))
+print("rgb bias got", grads[23].cpu().numpy(), "ref", d_raw[:, :3].sum(0).cpu().numpy())
+print("views bias got[:6]", grads[17].cpu().numpy()[:6], "ref", zv.grad.sum(0).cpu().numpy()[:6])
+print("sum |d_sigma|", float(d_raw[:, 3].abs().sum()))

@@ -19,8 +19,10 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     args = ap.parse_args()
     from nerf_loc_amd import helpers, render, synth, train
+    train.set_train_precision(args.precision)
     dev = torch.device("cuda:0")
 
     def net(seed):
@@ -44,7 +46,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     flop = args.rays * 256 * 1186816 * 3.0
-    print(json.dumps({"workload": "train step, %d rays, 64+128, fp32" % args.rays, "ms_per_iter": dt * 1e3,
+    print(json.dumps({"workload": "train step, %d rays, 64+128, %s" % (args.rays, args.precision), "ms_per_iter": dt * 1e3,
                       "rays_per_s": args.rays / dt, "tflops_3x_fwd": flop / dt / 1e12, "loss": float(loss)}))
 
 
