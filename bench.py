@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"],
+                    help="train workload only: float32 (what the reference computes) or bf16 MFMA operands")
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--chunk", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -196,9 +198,11 @@ def main():
         tgt_all = torch.rand(total, 3, generator=torch.Generator().manual_seed(0)).to(device)
         lo, hi, _ = ndist.shard_bounds(total, rank, world)
         rays_l, tgt_l = rays_all[lo:hi], tgt_all[lo:hi]
-        args.precision = "fp32"
+        args.precision = args.train_precision
+        train.set_train_precision(args.train_precision)
         desc = ("BASELINE configs[4]: training iteration, 4096 rays over %d GPU(s), 64 + 128 samples, stratified "
-                "jitter, forward + backward of both networks + one gradient all-reduce + Adam, float32" % world)
+                "jitter, forward + backward of both networks + one gradient all-reduce + Adam, %s"
+                % (world, "float32" if args.train_precision == "fp32" else "bf16 operands, float32 accumulation and parameters"))
         it = [0]
 
         def step():
@@ -253,9 +257,18 @@ def main():
                     "mlp_time_share": sum(ms) * 1e-3 / dt}
         else:   # training: forward-with-tape, input-gradient and weight-gradient kernels, timed as a whole step
             ach = n_rays * flop_per_ray * args.steps / dt / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                    "kernel": "whole iteration (mlp_f32_train_kernel + mlp_dgrad_f32_kernel + wgrad_kernel), "
-                              "3 x forward FLOPs per sample / step time"}
+            if args.precision == "bf16":
+                # tape traffic per sample: forward writes 158 pieces of 32 B, the input-gradient chain reads 136 and
+                # writes 156, the weight-gradient launches read 180 (gradients) + 178 (layer inputs)
+                tape_bytes = (158 + 136 + 156 + 180 + 178) * 32
+                gbs = n_rays * 192 * tape_bytes * args.steps / dt / 1e9
+                roof = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
+                        "kernel": "whole iteration (mlp_bf16_kernel<TAPE> + mlp_dgrad_bf16_kernel + wgrad16_kernel): "
+                                  "%d B of tape traffic per sample / step time; %.0f TFLOP/s at 3 x forward FLOPs" % (tape_bytes, ach)}
+            else:
+              roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                      "kernel": "whole iteration (mlp_f32_train_kernel + mlp_dgrad_f32_kernel + wgrad_kernel), "
+                                "3 x forward FLOPs per sample / step time"}
         line = {
             "metric": "rendered rays/sec (64+128 samples)" if args.workload in ("view", "rays4m") else
                       ("rendered rays/sec (64 samples, coarse only)" if args.workload == "objects" else "training rays/sec (64+128 samples, fwd+bwd+Adam)"),

@@ -32,7 +32,7 @@ struct EpiDgrad {
             for (int half = 0; half < 2; ++half)
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(t.act + (half * 2 + ct) * 1024);
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(t.act + (half * 2 + ct) * 1024));
                     mk[par][half][ct][0] = v[0]; mk[par][half][ct][1] = v[1];
                     mk[par][half][ct][2] = v[2]; mk[par][half][ct][3] = v[3];
                 }
@@ -49,7 +49,8 @@ struct EpiDgrad {
         return r;
     }
     __device__ __forceinline__ void store(const u32x4& v, const EpiTile& t, int half, int ct) const {
-        if (t.has_out) *reinterpret_cast<u32x4*>(t.out + (half * 2 + ct) * 1024) = v;
+        // streamed: 5 KB per sample must not push the weight stream out of L2 (0.69 -> 0.50 ms per forward launch)
+        if (t.has_out) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(t.out + (half * 2 + ct) * 1024));
     }
 };
 

@@ -278,3 +278,24 @@ def test_train_step_gradients(golden):
     assert abs(loss - float(g["stoch_loss"])) < 1e-6
     _check_grads(g, "stoch", "c", gc)
     _check_grads(g, "stoch", "f", gf)
+
+
+def test_bf16_restatement_of_the_network_backward():
+    """The bf16 variant of the oracle (checker of the bf16 training kernels; the reference has no such mode):
+    rounding is round-to-nearest-even on the upper 16 bits, and the gradients stay near the float64 ones."""
+    x = np.array([1.0, 1.00390625, 1.01171875, -3.14159274, 0.0, 1e-30], np.float32)
+    want = np.array([1.0, 1.0, 1.015625, -3.140625, 0.0, 1e-30], np.float32)
+    got = orc.bf16_round(x)
+    assert np.array_equal(got[:5].astype(np.float32), want[:5]) and abs(got[5] / 1e-30 - 1) < 2 ** -8
+    rs = np.random.RandomState(5)
+    from nerf_loc_amd import synth
+    sd = synth.make_state_dict(3, "B")
+    pts = rs.uniform(-2, 2, size=(300, 3)).astype(np.float32)
+    d = rs.normal(size=(300, 3))
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    feat = np.concatenate([orc.embed(pts, 10), orc.embed(d, 4)], -1)
+    d_raw = rs.randn(300, 4).astype(np.float32)
+    g64, g16 = orc.mlp_backward(sd, feat, d_raw), orc.mlp_backward(sd, feat, d_raw, bf16=True)
+    for k in g64:
+        rel = np.linalg.norm(g16[k] - g64[k]) / np.linalg.norm(g64[k])
+        assert rel < (0.02 if k.startswith(("rgb", "alpha")) else 0.25), (k, rel)
