@@ -38,13 +38,28 @@ __device__ unsigned long long g_stamps[256 * 8];
 // has in the registers (train_bf16.h).
 struct EpiTape {
     static constexpr bool ZERO_BIAS = false;
+    unsigned bits, ones;         // ReLU bits of the tile being converted; 0x00010001
     __device__ __forceinline__ void prefetch(const EpiTile&, int) {}
-    __device__ __forceinline__ unsigned post(unsigned v, const EpiTile&, int, int, int, int) const { return v; }
+    // the packed pair is non-negative after the clamp: min(bits, 1) per half is "unit active"
+    __device__ __forceinline__ unsigned post(unsigned v, const EpiTile& t, int, int half, int ct, int qd) {
+        if (t.has_act) {
+            unsigned m;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(v), "v"(ones));
+            const int k = 8 * ct + 4 * half + qd;
+            bits = k == 0 ? m : (bits | (m << k));
+        }
+        return v;
+    }
     __device__ __forceinline__ void store(const u32x4& v, const EpiTile& t, int half, int ct) const {
         // streamed: 5 KB per sample must not push the weight stream out of L2 (0.69 -> 0.50 ms per forward launch)
         if (t.has_out) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(t.out + (half * 2 + ct) * 1024));
+        if (t.has_act && half == 1 && ct == NCT - 1)      // the 8 words of a lane fill one 32-byte sector: let L2 merge them
+            *reinterpret_cast<unsigned*>(const_cast<unsigned char*>(t.act)) = bits;
     }
 };
+
+__device__ __forceinline__ void epi_init(EpiNone&) {}
+__device__ __forceinline__ void epi_init(EpiTape& e) { e.bits = 0u; e.ones = 0x00010001u; }
 
 template <bool VD, int OUT_CH, bool TAPE>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -132,40 +147,43 @@ void mlp_bf16_kernel(MlpArgs a) {
             }
         }
         typename std::conditional<TAPE, EpiTape, EpiNone>::type epi;
-        EpiTile carry{nullptr, nullptr, false, false};
+        epi_init(epi);
+        EpiTile carry{nullptr, nullptr, false, false, 0};
         auto out = [&](int piece) { return tw + piece * tape16::PIECE_BYTES; };
-#define NERF_L(NT, KPE, KH, KVW, hin, pdst, prelu, hasp, hout, relu, piece, store)                                     \
+        // ReLU bit words: 32 bytes per lane (tw carries 16 lane)
+        auto bitp = [&](int piece) { return tw + piece * tape16::PIECE_BYTES + lane * 16; };
+#define NERF_L(NT, KPE, KH, KVW, hin, pdst, prelu, hasp, hout, relu, piece, store, bpiece)                             \
     layer_bf16<NT, KPE, KH, KVW>(st, pos, bt, NB, h, bias, pe, hin, vw, accp, pdst, prelu, hasp, hout, relu, epi, carry, \
-                                 nullptr, false, out(piece), TAPE && (store))
+                                 bitp(bpiece), TAPE && (store) && (relu), out(piece), TAPE && (store))
         u32x4 A[16][NCT], B[16][NCT];
         f32x16 accp[2][NCT];     // accumulators of the current and of the previous output tile
         int pos = 0, bt = 0;
-        NERF_L(8, 4, 0, 0, A, A, false, false, A, true, tape16::h(VD, 0), true);        // L0: pe -> A
-        NERF_L(8, 0, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 1), true);    // L1
-        NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, true, tape16::h(VD, 2), true);    // L2
-        NERF_L(8, 0, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 3), true);    // L3
-        NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, true, tape16::h(VD, 4), true);    // L4
+        NERF_L(8, 4, 0, 0, A, A, false, false, A, true, tape16::h(VD, 0), true, tape16::bits(VD, 0));        // L0: pe -> A
+        NERF_L(8, 0, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 1), true, tape16::bits(VD, 1));    // L1
+        NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, true, tape16::h(VD, 2), true, tape16::bits(VD, 2));    // L2
+        NERF_L(8, 0, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 3), true, tape16::bits(VD, 3));    // L3
+        NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, true, tape16::h(VD, 4), true, tape16::bits(VD, 4));    // L4
         NERF_STAMP(t2)
-        NERF_L(8, 4, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 5), true);    // L5: [pe, h]
-        NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, true, tape16::h(VD, 6), true);    // L6
-        NERF_L(8, 0, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 7), true);    // L7 -> B
+        NERF_L(8, 4, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 5), true, tape16::bits(VD, 5));    // L5: [pe, h]
+        NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, true, tape16::h(VD, 6), true, tape16::bits(VD, 6));    // L6
+        NERF_L(8, 0, 16, 0, A, A + 14, true, true, B, true, tape16::h(VD, 7), true, tape16::bits(VD, 7));    // L7 -> B
 
         NERF_STAMP(t3)
         float o0[NCT], o1[NCT], o2[NCT], o3[NCT], o4[NCT];
         if (VD) {
-            NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, false, tape16::FEAT, true);   // feature -> A (no relu)
-            NERF_L(1, 0, 16, 0, B, A + 14, false, true, A, false, 0, false);            // alpha: row 3
+            NERF_L(8, 0, 16, 0, B, B + 14, true, true, A, false, tape16::FEAT, true, 0);   // feature -> A (no relu)
+            NERF_L(1, 0, 16, 0, B, A + 14, false, true, A, false, 0, false, 0);            // alpha: row 3
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) o3[ct] = accp[(bt - 1) & 1][ct][3];
-            NERF_L(4, 0, 16, 2, A, A, false, false, B, true, tape16::HV, true);         // views -> B[0..7]
-            NERF_L(1, 0, 8, 0, B, B + 6, true, true, B, false, 0, false);               // rgb: rows 0..2
+            NERF_L(4, 0, 16, 2, A, A, false, false, B, true, tape16::HV, true, tape16::bits(VD, 8));         // views -> B[0..7]
+            NERF_L(1, 0, 8, 0, B, B + 6, true, true, B, false, 0, false, 0);               // rgb: rows 0..2
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const f32x16& r = accp[(bt - 1) & 1][ct];
                 o0[ct] = r[0]; o1[ct] = r[1]; o2[ct] = r[2]; o4[ct] = 0.f;
             }
         } else {
-            NERF_L(1, 0, 16, 0, B, B + 14, true, true, B, false, 0, false);
+            NERF_L(1, 0, 16, 0, B, B + 14, true, true, B, false, 0, false, 0);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const f32x16& r = accp[(bt - 1) & 1][ct];

@@ -59,9 +59,11 @@ __device__ __forceinline__ unsigned pack_pair(float a, float b, bool relu) {
 // Tape view of one output tile for the lane: its two operand pieces (k-steps 2t, 2t+1 of the next layer) are four
 // 16-byte quads at [half][ct] * 1 KiB from these pointers.
 struct EpiTile {
-    const unsigned char* act;    // input-gradient chain: the forward activation of the tile (ReLU mask)
+    const unsigned char* act;    // the lane's word of ReLU bits of the tile: written by the training forward, read by
+                                 // the input-gradient chain
     unsigned char* out;          // where the packed tile is stored
     bool has_act, has_out;       // compile-time constants at every call site
+    int idx;                     // running number of the tile among the masked tiles of the pass (compile-time)
 };
 
 struct EpiNone {                 // inference: nothing leaves the registers
@@ -148,10 +150,12 @@ __device__ __forceinline__ void layer_bf16(Stream& st, int& pos, int& bt, int n_
                                            const u32x4 (*pe)[NCT], const u32x4 (*hin)[NCT], const u32x4 (*vw)[NCT],
                                            f32x16 (&accs)[2][NCT], u32x4 (*prev_dst)[NCT], bool prev_relu, bool has_prev,
                                            u32x4 (*hout)[NCT], bool relu, Epi& epi, EpiTile& carry,
-                                           const unsigned char* act0, bool has_act, unsigned char* out0, bool has_out) {
+                                           const unsigned char* act0, bool has_act, unsigned char* out0, bool has_out,
+                                           int idx0 = 0) {
+    constexpr int ACT_STRIDE = 4;        // the ReLU bit words of a layer: [lane 64][tile 8] dwords
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const EpiTile cur{act0 + t * 4096, out0 + t * 4096, has_act, has_out};
+        const EpiTile cur{act0 + t * ACT_STRIDE, out0 + t * 4096, has_act, has_out, idx0 + t};
         const int nb = Epi::ZERO_BIAS ? 0 : (bt + 1) % n_bias_tiles;
         if (t == 0)
             tile_bf16<KPE, KH, KVW, (KPE + KH + KVW >= 2)>(st, pos, h, nb, bias, pe, hin, vw, accs[bt & 1],

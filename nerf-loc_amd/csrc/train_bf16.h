@@ -20,7 +20,11 @@ constexpr int VW = 4;
 constexpr int h(bool vd, int i) { return (vd ? 6 : 4) + 16 * i; }
 constexpr int FEAT = 6 + 128;
 constexpr int HV = FEAT + 16;
-constexpr int total(bool vd) { return vd ? HV + 8 : 4 + 128; }
+// ReLU masks, one piece per layer with a ReLU (pts_linears.0-7, then views_linears.0): [lane 64][tile 8] dwords, bit
+// 8 ct + 4 half + qd (+ 16 for the upper bf16) of a lane's dword <-> the unit in packed dword qd of operand quad
+// [half][ct] of that tile.  The input-gradient chain reads these instead of the activations.
+constexpr int bits(bool vd, int i) { return (vd ? HV + 8 : 4 + 128) + i; }
+constexpr int total(bool vd) { return vd ? HV + 8 + 9 : 4 + 128 + 8; }
 // gradient tape: pre-activation gradients of pts_linears.0-7 (16 pieces each), of feature_linear (16), of
 // views_linears.0 (8), and the heads' output gradients padded to 32 rows (2 pieces each)
 constexpr int dz(int i) { return 16 * i; }

@@ -5,8 +5,8 @@
 //   forward            mlp_bf16_kernel<.., TAPE> (mlp.hip): the inference kernel, which also stores every layer input
 //                      as the packed operand quads it already holds (train_bf16.h)
 //   input gradients    mlp_dgrad_bf16_kernel: the same register-resident layer loop on the transposed weights; the
-//                      epilogue multiplies the packed gradient by the ReLU mask of the forward activation (2 VALU ops
-//                      per dword) and stores it in the same piece layout
+//                      epilogue multiplies the packed gradient by the ReLU bits the forward left (one word per
+//                      tile and lane) and stores it in the same piece layout
 //   weight gradients   wgrad16_kernel: dW[out, in] = sum_m G[m, out] X[m, in] with the sample as the MFMA k index.
 //                      Tapes are sample-on-lane; the k index must be in the register.  Pieces are copied to LDS as
 //                      they are (LDS-DMA) and read back with ds_read_b64_tr_b16, which hands each lane 4 samples of
@@ -24,32 +24,21 @@ using namespace tape16;
 // ------------------------------------------------------------------------------------------
 struct EpiDgrad {
     static constexpr bool ZERO_BIAS = true;
-    unsigned mk[2][2][NCT][4];   // forward activations of the two tiles in flight: [tile parity][half][ct][dword]
+    unsigned bits[72];           // ReLU bit words (train_bf16.h) of every masked tile of the pass, loaded at its start:
+                                 // no vector-memory load (and so no wait on the tape stores) inside the layer loop
     unsigned ones;               // 0x00010001
-    __device__ __forceinline__ void prefetch(const EpiTile& t, int par) {
-        if (t.has_act) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(t.act + (half * 2 + ct) * 1024));
-                    mk[par][half][ct][0] = v[0]; mk[par][half][ct][1] = v[1];
-                    mk[par][half][ct][2] = v[2]; mk[par][half][ct][3] = v[3];
-                }
-        }
-    }
-    // The activations are non-negative bf16: min(bits, 1) is 1 where the unit was active, and the 16-bit product
-    // keeps or clears each half of the packed gradient.  Written as instructions: left to the compiler the pair
-    // becomes compare / select chains of three times the length.
-    __device__ __forceinline__ unsigned post(unsigned v, const EpiTile& t, int par, int half, int ct, int qd) const {
+    __device__ __forceinline__ void prefetch(const EpiTile&, int) {}
+    // Bit 8 ct + 4 half + qd (+ 16) says whether the lower (upper) unit of this packed dword was active in the
+    // forward pass; the 16-bit product keeps or clears each half of the packed gradient.  Written as an instruction:
+    // left to the compiler the multiply becomes compare / select chains.
+    __device__ __forceinline__ unsigned post(unsigned v, const EpiTile& t, int, int half, int ct, int qd) const {
         if (!t.has_act) return v;
-        unsigned m, r;
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(mk[par][half][ct][qd]), "v"(ones));
+        const unsigned m = (bits[t.idx] >> (8 * ct + 4 * half + qd)) & ones;
+        unsigned r;
         asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
         return r;
     }
     __device__ __forceinline__ void store(const u32x4& v, const EpiTile& t, int half, int ct) const {
-        // streamed: 5 KB per sample must not push the weight stream out of L2 (0.69 -> 0.50 ms per forward launch)
         if (t.has_out) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(t.out + (half * 2 + ct) * 1024));
     }
 };
@@ -110,7 +99,22 @@ void mlp_dgrad_bf16_kernel(Dgrad16Args a) {
         const unsigned long long blk = (unsigned long long)(tile * 4 + wave);
         const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)blk), bhi = __builtin_amdgcn_readfirstlane((unsigned)(blk >> 32));
         const unsigned long long blk_u = ((unsigned long long)bhi << 32) | blo;
-        const unsigned char* tw = a.tape + blk_u * (total(VD) * PIECE_BYTES) + lane * 16;
+        {   // ReLU bit words of the pass: 32 bytes per lane and layer; the layer used first is loaded last, so the one
+            // wait in front of its first use covers them all
+            const unsigned char* bw = a.tape + blk_u * (total(VD) * PIECE_BYTES) + lane * 32;
+#pragma unroll
+            for (int i = 0; i < (VD ? 9 : 8); ++i) {
+                const u32x4* p = reinterpret_cast<const u32x4*>(bw + bits(VD, i) * PIECE_BYTES);
+                const u32x4 v0 = __builtin_nontemporal_load(p);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) epi.bits[8 * i + k] = v0[k];
+                if (i < 8) {                                   // views_linears.0 has four tiles
+                    const u32x4 v1 = __builtin_nontemporal_load(p + 1);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) epi.bits[8 * i + 4 + k] = v1[k];
+                }
+            }
+        }
         unsigned char* gw = a.gtape + blk_u * (gtotal(VD) * PIECE_BYTES) + lane * 16;
 
         // head gradients as one-k-step operands: slot (h, j) <-> row 8 (j >> 2) + 4 h + (j & 3); stored padded to
@@ -146,25 +150,25 @@ void mlp_dgrad_bf16_kernel(Dgrad16Args a) {
         u32x4 A[16][NCT], B[16][NCT];
         f32x16 accp[2][NCT];
         f32x16 bias = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        EpiTile carry{nullptr, nullptr, false, false};
+        EpiTile carry{nullptr, nullptr, false, false, 0};
         int pos = 0, bt = 0;
-#define NERF_D(NT, KPE, KH, KVW, hin, pdst, hasp, hout, act_piece, masked, out_piece)                                  \
+#define NERF_D(NT, KPE, KH, KVW, hin, pdst, hasp, hout, layer, masked, out_piece)                                  \
     layer_bf16<NT, KPE, KH, KVW>(st, pos, bt, 1, h, bias, g0, hin, g1, accp, pdst, false, hasp, hout, false, epi, carry, \
-                                 tw + (act_piece) * PIECE_BYTES, masked, gw + (out_piece) * PIECE_BYTES, true)
+                                 nullptr, masked, gw + (out_piece) * PIECE_BYTES, true, 8 * (layer))
         if (VD) {
-            NERF_D(4, 1, 0, 0, A, A, false, B, HV, true, DZV);             // rgb_linear^T: d(rgb) -> d(view hidden)
+            NERF_D(4, 1, 0, 0, A, A, false, B, 8, true, DZV);             // rgb_linear^T: d(rgb) -> d(view hidden)
             NERF_D(8, 0, 8, 0, B, B + 6, true, A, 0, false, DFEAT);        // views_linears.0^T (feature columns)
-            NERF_D(8, 0, 16, 1, A, A + 14, true, B, tape16::h(VD, 7), true, dz(7)); // feature_linear^T + alpha_linear^T
+            NERF_D(8, 0, 16, 1, A, A + 14, true, B, 7, true, dz(7)); // feature_linear^T + alpha_linear^T
         } else {
-            NERF_D(8, 1, 0, 0, A, A, false, B, tape16::h(VD, 7), true, dz(7));     // output_linear^T
+            NERF_D(8, 1, 0, 0, A, A, false, B, 7, true, dz(7));     // output_linear^T
         }
-        NERF_D(8, 0, 16, 0, B, B + 14, true, A, tape16::h(VD, 6), true, dz(6));    // pts_linears.7^T
-        NERF_D(8, 0, 16, 0, A, A + 14, true, B, tape16::h(VD, 5), true, dz(5));    // .6
-        NERF_D(8, 0, 16, 0, B, B + 14, true, A, tape16::h(VD, 4), true, dz(4));    // .5 (hidden columns)
-        NERF_D(8, 0, 16, 0, A, A + 14, true, B, tape16::h(VD, 3), true, dz(3));    // .4
-        NERF_D(8, 0, 16, 0, B, B + 14, true, A, tape16::h(VD, 2), true, dz(2));    // .3
-        NERF_D(8, 0, 16, 0, A, A + 14, true, B, tape16::h(VD, 1), true, dz(1));    // .2
-        NERF_D(8, 0, 16, 0, B, B + 14, true, A, tape16::h(VD, 0), true, dz(0));    // .1
+        NERF_D(8, 0, 16, 0, B, B + 14, true, A, 6, true, dz(6));    // pts_linears.7^T
+        NERF_D(8, 0, 16, 0, A, A + 14, true, B, 5, true, dz(5));    // .6
+        NERF_D(8, 0, 16, 0, B, B + 14, true, A, 4, true, dz(4));    // .5 (hidden columns)
+        NERF_D(8, 0, 16, 0, A, A + 14, true, B, 3, true, dz(3));    // .4
+        NERF_D(8, 0, 16, 0, B, B + 14, true, A, 2, true, dz(2));    // .3
+        NERF_D(8, 0, 16, 0, A, A + 14, true, B, 1, true, dz(1));    // .2
+        NERF_D(8, 0, 16, 0, B, B + 14, true, A, 0, true, dz(0));    // .1
 #undef NERF_D
         // the last tile has no successor to hide its epilogue under
 #pragma unroll
