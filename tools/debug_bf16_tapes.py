@@ -90,7 +90,7 @@ def cmp(name, got, ref, scaled=False):
     print("%-10s scale %-10g rel max err %.3e   (|ref| max %.3e)" % (name, sc, err, np.abs(ref).max()))
 
 
-T = 158
+T = 167          # forward pieces per (tile, wave): tape16::total(true)
 hs = [torch.relu(zi) for zi in z]
 for i in range(8):
     cmp("h%d" % i, decode(tape, T, 6 + 16 * i, 16), hs[i], True)
