@@ -98,6 +98,36 @@ def test_invalid_arguments_are_refused_before_any_launch():
                                None, 0, None, None, None, None, None) == -1
 
 
+def test_training_entry_points_check_precision_and_sizes():
+    """Host-only checks of the training side of the ABI: tape sizes per precision, unknown precisions refused."""
+    lib = hip.lib()
+    f32, b16 = hip.PREC_F32, hip.PREC_BF16
+    # float32 tapes: sample-major rows padded to 128 samples (pe 64 + view 32 + 8 x 256 + 256 + 128 floats)
+    assert lib.nerf_train_tape_bytes(1, 1, f32) == 128 * (64 + 32 + 8 * 256 + 256 + 128) * 4
+    assert lib.nerf_train_grad_tape_bytes(1, 1, f32) == 128 * (8 * 256 + 256 + 128) * 4
+    # bf16 tapes: 2 KiB operand pieces per 64 samples, padded to 256 samples (167 / 156 with view directions)
+    assert lib.nerf_train_tape_bytes(1, 1, b16) == 4 * 167 * 2048
+    assert lib.nerf_train_tape_bytes(257, 0, b16) == 8 * 140 * 2048
+    assert lib.nerf_train_grad_tape_bytes(256, 1, b16) == 4 * 156 * 2048
+    assert lib.nerf_train_grad_tape_bytes(256, 0, b16) == 4 * 130 * 2048
+    assert lib.nerf_mlp_backward_packed_bytes(1, f32) == 2192 * 1024 and lib.nerf_mlp_backward_packed_bytes(0, f32) == 1808 * 1024
+    assert lib.nerf_mlp_backward_packed_bytes(1, b16) == 1104 * 1024 and lib.nerf_mlp_backward_packed_bytes(0, b16) == 912 * 1024
+    for fn in (lib.nerf_train_tape_bytes, lib.nerf_train_grad_tape_bytes):
+        assert fn(100, 1, 7) == 0 and fn(-1, 1, f32) == 0
+    assert lib.nerf_mlp_backward_packed_bytes(1, 7) == 0
+    p = ctypes.c_void_p(256)
+    arr = (ctypes.c_void_p * 24)(*[256] * 24)
+    assert lib.nerf_mlp_pack_backward(arr, 1, 4, 7, p, None) == -1
+    assert b"precision" in lib.nerf_last_error()
+    fp = ctypes.cast(p, ctypes.POINTER(ctypes.c_float))
+    assert lib.nerf_mlp_forward_train(p, 7, 1, 4, 0, fp, None, 8, 1, 0, fp, p, None) == -1
+    assert lib.nerf_mlp_backward(p, None, b16, 1, 4, fp, 8, p, p, fp, 1 << 30, arr, None) == -1      # no forward stream
+    assert b"forward stream" in lib.nerf_last_error()
+    with pytest.raises(ValueError):
+        from nerf_loc_amd import train
+        train.set_train_precision("fp8")
+
+
 def test_missing_library_fails_loudly():
     code = ("import nerf_loc_amd\nfrom nerf_loc_amd import hip\n"
             "try:\n    hip.lib()\nexcept hip.NerfHipError as e:\n    print('LOUD', e)\n")
