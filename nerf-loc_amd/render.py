@@ -304,6 +304,13 @@ def create_nerf(args, device=None):
         model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
                           skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
         grad_vars += list(model_fine.parameters())
+    # not a reference option: args.train_precision = "bf16" trains with bf16 MFMA operands (float32 otherwise)
+    train_precision = getattr(args, 'train_precision', None)
+    if train_precision not in (None, "fp32", "bf16"):
+        raise ValueError("train_precision must be 'fp32' or 'bf16', got %r" % (train_precision,))
+    for m in (model, model_fine):
+        if m is not None and train_precision is not None:
+            m.train_precision = train_precision
     network_query_fn = NetworkQuery(embed_fn, embeddirs_fn, args.netchunk)
     from .train import FusedAdam      # torch.optim.Adam's update and state layout, one launch per step
     optimizer = FusedAdam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
