@@ -22,8 +22,9 @@ def _grads(net, feat, d_raw, prec):
     return out.detach(), {k: N(p.grad).astype(np.float64) for k, p in net.named_parameters() if p.grad is not None}
 
 
-@pytest.mark.parametrize("M", [77, 1000, 40000])
-@pytest.mark.parametrize("vd,och", [(True, 4), (False, 4), (False, 5)])
+@pytest.mark.parametrize("M,vd,och", [(77, True, 4), (1000, True, 4), (40000, True, 4), (77, False, 4), (1000, False, 4),
+                                      (40000, False, 4), (77, False, 5), (1000, False, 5), (40000, False, 5),
+                                      (70001, True, 4)])      # the last one: some workgroups run two passes
 def test_bf16_network_backward(dev, M, vd, och):
     sd = synth.make_state_dict(70 + M % 7, "B") if vd else synth.make_state_dict(70 + M % 7, "B", use_viewdirs=False, output_ch=och, input_ch_views=0)
     net = load_net(sd, dev, use_viewdirs=vd, output_ch=och)
