@@ -259,8 +259,8 @@ def main():
             ach = n_rays * flop_per_ray * args.steps / dt / 1e12
             if args.precision == "bf16":
                 # tape traffic per sample: forward writes 167 pieces of 32 B (9 of them ReLU bits), the input-gradient
-                # chain reads those 9 and writes 156, the weight-gradient launches read 180 (gradients) + 178 (inputs)
-                tape_bytes = (167 + 9 + 156 + 180 + 178) * 32
+                # chain reads those 9 and writes 156, the weight-gradient launches read 156 (gradients) + 178 (inputs)
+                tape_bytes = (167 + 9 + 156 + 156 + 178) * 32
                 gbs = n_rays * 192 * tape_bytes * args.steps / dt / 1e9
                 roof = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
                         "kernel": "whole iteration (mlp_bf16_kernel<TAPE> + mlp_dgrad_bf16_kernel + wgrad16_kernel): "

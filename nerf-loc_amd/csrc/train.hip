@@ -368,7 +368,7 @@ extern "C" size_t nerf_train_grad_tape_bytes(long long M, int use_viewdirs, int 
     return (size_t)pad128(M) * gtape_floats(use_viewdirs != 0) * sizeof(float);
 }
 extern "C" size_t nerf_train_workspace_bytes(void) {
-    return ((size_t)WG_MAX_PARTS * 256 * 256 + (size_t)WG_MAX_PARTS * 256) * sizeof(float);
+    return (WG_BIAS_OFFSET + (size_t)WG_MAX_PARTS * 256) * sizeof(float);
 }
 extern "C" size_t nerf_mlp_backward_packed_bytes(int use_viewdirs, int precision) {
     if (!known_precision(precision)) return 0;

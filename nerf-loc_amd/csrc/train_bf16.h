@@ -13,18 +13,20 @@ namespace nerf {
 namespace tape16 {
 
 constexpr int PIECE_BYTES = 2048;
-// forward tape: encoded points (4 pieces, kernel k-slot order), encoded view (2), the outputs of pts_linears.0-7
-// (16 each, scaled as the forward keeps them), feature_linear's output (16), views_linears.0's output (8)
-constexpr int PE = 0;
-constexpr int VW = 4;
-constexpr int h(bool vd, int i) { return (vd ? 6 : 4) + 16 * i; }
-constexpr int FEAT = 6 + 128;
-constexpr int HV = FEAT + 16;
+// forward tape: the outputs of pts_linears.0-4 (16 pieces each, scaled as the forward keeps them), the encoded points
+// (4 pieces, kernel k-slot order), pts_linears.5-7, feature_linear's output (16), the encoded view (2),
+// views_linears.0's output (8).  The order makes the input of every layer one contiguous run of pieces:
+// pts_linears.5 reads [h4, points] (20 pieces), views_linears.0 reads [feature, view] (18).
+constexpr int PE = 80;
+constexpr int h(bool, int i) { return i <= 4 ? 16 * i : 84 + 16 * (i - 5); }
+constexpr int FEAT = 132;
+constexpr int VW = 148;
+constexpr int HV = 150;
 // ReLU masks, one piece per layer with a ReLU (pts_linears.0-7, then views_linears.0): [lane 64][tile 8] dwords, bit
 // 8 ct + 4 half + qd (+ 16 for the upper bf16) of a lane's dword <-> the unit in packed dword qd of operand quad
 // [half][ct] of that tile.  The input-gradient chain reads these instead of the activations.
-constexpr int bits(bool vd, int i) { return (vd ? HV + 8 : 4 + 128) + i; }
-constexpr int total(bool vd) { return vd ? HV + 8 + 9 : 4 + 128 + 8; }
+constexpr int bits(bool vd, int i) { return (vd ? HV + 8 : 132) + i; }
+constexpr int total(bool vd) { return vd ? HV + 8 + 9 : 132 + 8; }
 // gradient tape: pre-activation gradients of pts_linears.0-7 (16 pieces each), of feature_linear (16), of
 // views_linears.0 (8), and the heads' output gradients padded to 32 rows (2 pieces each)
 constexpr int dz(int i) { return 16 * i; }

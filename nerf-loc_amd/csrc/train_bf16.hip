@@ -295,7 +295,9 @@ void wgrad16_kernel(Wg16Args a) {
             const unsigned sbase1 = lds0 + ((unsigned)i % NST) * SB + lane_rd1;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {                            // 16 samples per MFMA
-                bf16x8 ga[RT], xb[CT];
+                // wide X (10 tiles: 320 + 32 accumulators) is taken in two halves to keep the operand registers few
+                constexpr int CG = CT > 8 ? (CT + 1) / 2 : CT;
+                bf16x8 ga[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     const int ft = wave * RT + rt;
@@ -304,18 +306,26 @@ void wgrad16_kernel(Wg16Args a) {
                     ga[rt] = __builtin_bit_cast(bf16x8, v);
                 }
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const s16x4 lo = tr_read(sbase, PG * 1024 + ct * 2048 + kk * 256), hi = tr_read(sbase1, PG * 1024 + ct * 2048 + kk * 256);
-                    const short __attribute__((ext_vector_type(8))) v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    xb[ct] = __builtin_bit_cast(bf16x8, v);
+                for (int c0 = 0; c0 < CT; c0 += CG) {
+                    bf16x8 xb[CG];
+#pragma unroll
+                    for (int j = 0; j < CG; ++j) {
+                        const int ct = c0 + j < CT ? c0 + j : CT - 1;
+                        const s16x4 lo = tr_read(sbase, PG * 1024 + ct * 2048 + kk * 256), hi = tr_read(sbase1, PG * 1024 + ct * 2048 + kk * 256);
+                        const short __attribute__((ext_vector_type(8))) v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        xb[j] = __builtin_bit_cast(bf16x8, v);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int j = 0; j < CG; ++j)
+                            if (c0 + j < CT)
+                                acc[rt][c0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[rt], xb[j], acc[rt][c0 + j], 0, 0, 0);
+                    if (CT > 8) __builtin_amdgcn_sched_barrier(0);      // keep the halves apart
                 }
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[rt], xb[ct], acc[rt][ct], 0, 0, 0);
+                for (int rt = 0; rt < RT; ++rt)
                     bacc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[rt], __builtin_bit_cast(bf16x8, ones4), bacc[rt], 0, 0, 0);
-                }
             }
         }
     }
@@ -341,11 +351,10 @@ void wgrad16_kernel(Wg16Args a) {
     }
 }
 
-// G: `pg` pieces from piece g_piece of the gradient tape; X: 2 ct pieces from piece x_piece of the forward tape.
-// dW[n_rows, ld] (columns through `map`, from col_off) = sum / *x_scale; db[n_rows] = column sums of G.
+// First phase: G = `pg` pieces from piece g_piece of the gradient tape, X = 2 ct pieces from piece x_piece of the
+// forward tape; partial tiles [parts][256][32 ct] (and bias partials) go to ws.  Returns the number of parts.
 static int launch_wgrad16(const unsigned char* gtape, bool vd, int g_piece, int pg, const unsigned char* tape, int x_piece,
-                          int ct, long long m_pad, float* ws, float* dW, int n_rows, int k_emit, int ld, int col_off, int map,
-                          const float* x_scale, float* db, hipStream_t st) {
+                          int ct, long long m_pad, float* ws, bool want_bias, hipStream_t st, int* parts_out) {
     const int n_chunks = (int)(m_pad / 32);
     int parts = n_chunks / 8;                         // at least 8 chunks (256 samples) per workgroup
     if (parts > WG_MAX_PARTS) parts = WG_MAX_PARTS;
@@ -353,22 +362,24 @@ static int launch_wgrad16(const unsigned char* gtape, bool vd, int g_piece, int 
     if (parts < 1) parts = 1;
     const int per_wg = (n_chunks + parts - 1) / parts;
     parts = (n_chunks + per_wg - 1) / per_wg;
+    NERF_REQUIRE(32 * ct <= WG_PART_COLS, "weight gradient (bf16): %d column tiles exceed the workspace", ct);
     Wg16Args a{gtape, (unsigned)(gtotal(vd) * PIECE_BYTES), (unsigned)(g_piece * PIECE_BYTES),
                tape, (unsigned)(total(vd) * PIECE_BYTES), (unsigned)(x_piece * PIECE_BYTES),
-               n_chunks, per_wg, ws, db ? ws + (size_t)WG_MAX_PARTS * 256 * 256 : nullptr};
+               n_chunks, per_wg, ws, want_bias ? ws + WG_BIAS_OFFSET : nullptr};
     const dim3 grid((unsigned)parts), block(256);
     const int key = pg * 16 + ct;
     switch (key) {
         case 16 * 16 + 8: hipLaunchKernelGGL((wgrad16_kernel<16, 8>), grid, block, 0, st, a); break;
+        case 16 * 16 + 10: hipLaunchKernelGGL((wgrad16_kernel<16, 10>), grid, block, 0, st, a); break;
         case 16 * 16 + 2: hipLaunchKernelGGL((wgrad16_kernel<16, 2>), grid, block, 0, st, a); break;
-        case 8 * 16 + 8: hipLaunchKernelGGL((wgrad16_kernel<8, 8>), grid, block, 0, st, a); break;
-        case 8 * 16 + 1: hipLaunchKernelGGL((wgrad16_kernel<8, 1>), grid, block, 0, st, a); break;
+        case 8 * 16 + 9: hipLaunchKernelGGL((wgrad16_kernel<8, 9>), grid, block, 0, st, a); break;
         case 2 * 16 + 8: hipLaunchKernelGGL((wgrad16_kernel<2, 8>), grid, block, 0, st, a); break;
         case 2 * 16 + 4: hipLaunchKernelGGL((wgrad16_kernel<2, 4>), grid, block, 0, st, a); break;
         default: NERF_REQUIRE(false, "weight gradient (bf16): unsupported shape %d pieces x %d tiles", pg, ct);
     }
     NERF_LAUNCH_CHECK();
-    return launch_wgrad_reduce(ws, parts, 32 * ct, n_rows, k_emit, dW, ld, col_off, map, x_scale, db, st);
+    *parts_out = parts;
+    return NERF_OK;
 }
 
 size_t tape16_bytes(long long M, bool vd) { return (size_t)(pad256(M) / 64) * total(vd) * PIECE_BYTES; }
@@ -415,20 +426,35 @@ int backward_bf16(const void* packed_bwd, const void* packed_fwd, bool vd, int o
     const long long mp = pad256(M);
     int rc;
 #define NERF_TRY(x) do { rc = (x); if (rc != NERF_OK) return rc; } while (0)
-    NERF_TRY(launch_wgrad16(gtape, vd, dz(0), 16, tape, PE, 2, mp, ws, g[0], 256, 64, 63, 0, 3, nullptr, g[1], st));
+    // (kernel, then one reduction per run of columns of the parameter tensor; maps 3 / 4 put the encoded-input
+    //  columns of the bf16 operand order back into reference order)
+    int parts = 0;
+    NERF_TRY(launch_wgrad16(gtape, vd, dz(0), 16, tape, PE, 2, mp, ws, true, st, &parts));
+    NERF_TRY(launch_wgrad_reduce(ws, parts, 64, 0, 256, 64, g[0], 63, 0, 3, nullptr, g[1], st));
     for (int i = 1; i < 8; ++i) {
-        const int ld = i == 5 ? 319 : 256, off = i == 5 ? 63 : 0;
-        NERF_TRY(launch_wgrad16(gtape, vd, dz(i), 16, tape, h(vd, i - 1), 8, mp, ws, g[2 * i], 256, 256, ld, off, 0, sc + (i - 1), g[2 * i + 1], st));
-        if (i == 5) NERF_TRY(launch_wgrad16(gtape, vd, dz(5), 16, tape, PE, 2, mp, ws, g[10], 256, 64, 319, 0, 3, nullptr, nullptr, st));
+        if (i == 5) {   // pts_linears.5 reads [encoded points, h4]: one pass over [h4, points] on the tape
+            NERF_TRY(launch_wgrad16(gtape, vd, dz(5), 16, tape, h(vd, 4), 10, mp, ws, true, st, &parts));
+            NERF_TRY(launch_wgrad_reduce(ws, parts, 320, 0, 256, 256, g[10], 319, 63, 0, sc + 4, g[11], st));
+            NERF_TRY(launch_wgrad_reduce(ws, parts, 320, 256, 256, 64, g[10], 319, 0, 3, nullptr, nullptr, st));
+            continue;
+        }
+        NERF_TRY(launch_wgrad16(gtape, vd, dz(i), 16, tape, h(vd, i - 1), 8, mp, ws, true, st, &parts));
+        NERF_TRY(launch_wgrad_reduce(ws, parts, 256, 0, 256, 256, g[2 * i], 256, 0, 0, sc + (i - 1), g[2 * i + 1], st));
     }
     if (vd) {
-        NERF_TRY(launch_wgrad16(gtape, vd, DFEAT, 16, tape, h(vd, 7), 8, mp, ws, g[18], 256, 256, 256, 0, 0, sc + 7, g[19], st));
-        NERF_TRY(launch_wgrad16(gtape, vd, DZV, 8, tape, FEAT, 8, mp, ws, g[16], 128, 256, 283, 0, 0, sc + 8, g[17], st));
-        NERF_TRY(launch_wgrad16(gtape, vd, DZV, 8, tape, VW, 1, mp, ws, g[16], 128, 32, 283, 256, 4, nullptr, nullptr, st));
-        NERF_TRY(launch_wgrad16(gtape, vd, DSIG, 2, tape, h(vd, 7), 8, mp, ws, g[20], 1, 256, 256, 0, 0, sc + 7, g[21], st));
-        NERF_TRY(launch_wgrad16(gtape, vd, DRGB, 2, tape, HV, 4, mp, ws, g[22], 3, 128, 128, 0, 0, sc + 9, g[23], st));
+        NERF_TRY(launch_wgrad16(gtape, vd, DFEAT, 16, tape, h(vd, 7), 8, mp, ws, true, st, &parts));
+        NERF_TRY(launch_wgrad_reduce(ws, parts, 256, 0, 256, 256, g[18], 256, 0, 0, sc + 7, g[19], st));
+        // views_linears.0 reads [feature, encoded view]: contiguous on the tape
+        NERF_TRY(launch_wgrad16(gtape, vd, DZV, 8, tape, FEAT, 9, mp, ws, true, st, &parts));
+        NERF_TRY(launch_wgrad_reduce(ws, parts, 288, 0, 128, 256, g[16], 283, 0, 0, sc + 8, g[17], st));
+        NERF_TRY(launch_wgrad_reduce(ws, parts, 288, 256, 128, 32, g[16], 283, 256, 4, nullptr, nullptr, st));
+        NERF_TRY(launch_wgrad16(gtape, vd, DSIG, 2, tape, h(vd, 7), 8, mp, ws, true, st, &parts));
+        NERF_TRY(launch_wgrad_reduce(ws, parts, 256, 0, 1, 256, g[20], 256, 0, 0, sc + 7, g[21], st));
+        NERF_TRY(launch_wgrad16(gtape, vd, DRGB, 2, tape, HV, 4, mp, ws, true, st, &parts));
+        NERF_TRY(launch_wgrad_reduce(ws, parts, 128, 0, 3, 128, g[22], 128, 0, 0, sc + 9, g[23], st));
     } else {
-        NERF_TRY(launch_wgrad16(gtape, vd, DOUT, 2, tape, h(vd, 7), 8, mp, ws, g[18], output_ch, 256, 256, 0, 0, sc + 7, g[19], st));
+        NERF_TRY(launch_wgrad16(gtape, vd, DOUT, 2, tape, h(vd, 7), 8, mp, ws, true, st, &parts));
+        NERF_TRY(launch_wgrad_reduce(ws, parts, 256, 0, output_ch, 256, g[18], 256, 0, 0, sc + 7, g[19], st));
     }
 #undef NERF_TRY
     return NERF_OK;

@@ -5,6 +5,9 @@
 namespace nerf {
 
 constexpr int WG_MAX_PARTS = 256;      // workgroups of a weight-gradient launch
+constexpr int WG_PART_COLS = 320;      // widest partial tile: 256 hidden + 64 encoded-point columns (pts_linears.5)
+// workspace: [WG_MAX_PARTS][256][<= WG_PART_COLS] partial tiles, then [WG_MAX_PARTS][256] bias partials
+constexpr size_t WG_BIAS_OFFSET = (size_t)WG_MAX_PARTS * 256 * WG_PART_COLS;
 
 // dW[n, ld*] (+ db[n]) = sum over the M rows of G[m, n] X[m, k]; ws: nerf_train_workspace_bytes() of scratch.
 // map: 0 identity, 1 encoded-point k-slot -> reference column, 2 encoded-view k-slot -> reference column.
@@ -14,11 +17,12 @@ int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K,
 int launch_wgrad_small(const float* d_raw, int ldr, int c0, int N, const float* X, int K, long long M, float* ws,
                        float* dW, float* db, hipStream_t st);
 
-// Second phase alone, for partial tiles [parts][256][pcol] in ws (bias partials behind them as in launch_wgrad):
+// Second phase alone, for columns pcol0 .. pcol0 + k_emit - 1 of partial tiles [parts][256][pcol] in ws (bias
+// partials at WG_BIAS_OFFSET):
 // maps 3 / 4 are the encoded-point / encoded-view columns in the bf16 operand order; *x_scale (device pointer or
 // null) is a power of two the inputs were stored multiplied by.
-int launch_wgrad_reduce(const float* ws, int parts, int pcol, int n_rows, int k_emit, float* dW, int ld, int col_off,
-                        int map, const float* x_scale, float* db, hipStream_t st);
+int launch_wgrad_reduce(const float* ws, int parts, int pcol, int pcol0, int n_rows, int k_emit, float* dW, int ld,
+                        int col_off, int map, const float* x_scale, float* db, hipStream_t st);
 
 // bf16 training (train_bf16.hip)
 size_t tape16_bytes(long long M, bool vd);

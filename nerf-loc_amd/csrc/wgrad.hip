@@ -170,10 +170,10 @@ __global__ void wgrad_reduce_kernel(ReduceArgs a) {
     a.dst[(size_t)row * a.ld + a.col_off + dc] = sum;
 }
 
-int launch_wgrad_reduce(const float* ws, int parts, int pcol, int n_rows, int k_emit, float* dW, int ld, int col_off,
-                        int map, const float* x_scale, float* db, hipStream_t st) {
-    ReduceArgs r{ws, parts, 256, pcol, n_rows, k_emit, dW, ld, col_off, map, x_scale,
-                 ws + (size_t)WG_MAX_PARTS * 256 * 256, db};
+int launch_wgrad_reduce(const float* ws, int parts, int pcol, int pcol0, int n_rows, int k_emit, float* dW, int ld,
+                        int col_off, int map, const float* x_scale, float* db, hipStream_t st) {
+    ReduceArgs r{ws + pcol0, parts, 256, pcol, n_rows, k_emit, dW, ld, col_off, map, x_scale,
+                 ws + WG_BIAS_OFFSET, db};
     const int cols = k_emit > n_rows ? k_emit : n_rows;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cols + 63) / 64, n_rows + (db ? 1 : 0)), dim3(64), 0, st, r);
     NERF_LAUNCH_CHECK();
@@ -192,7 +192,7 @@ int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K,
     long long chunk = (M + parts - 1) / parts;
     chunk += chunk & 1;
     parts = (M + chunk - 1) / chunk;
-    WgradArgs a{G, ldg, N, X, ldx, K, M, chunk, ws, db ? ws + (size_t)WG_MAX_PARTS * 256 * 256 : nullptr};
+    WgradArgs a{G, ldg, N, X, ldx, K, M, chunk, ws, db ? ws + WG_BIAS_OFFSET : nullptr};
     const int ctp = ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : 8;
     dim3 grid((unsigned)parts), block(256);
     switch (ctp) {

@@ -93,8 +93,8 @@ def cmp(name, got, ref, scaled=False):
 T = 167          # forward pieces per (tile, wave): tape16::total(true)
 hs = [torch.relu(zi) for zi in z]
 for i in range(8):
-    cmp("h%d" % i, decode(tape, T, 6 + 16 * i, 16), hs[i], True)
-cmp("feat", decode(tape, T, 134, 16), f, True)
+    cmp("h%d" % i, decode(tape, T, 16 * i if i <= 4 else 84 + 16 * (i - 5), 16), hs[i], True)
+cmp("feat", decode(tape, T, 132, 16), f, True)
 cmp("hv", decode(tape, T, 150, 8), hv, True)
 G = 156
 cmp("dzv", decode(gt, G, 144, 8), zv.grad)
