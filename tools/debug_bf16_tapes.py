@@ -28,7 +28,6 @@ for i in range(8):
     zi = (h @ W["pts_linears.%d.weight" % i].T + W["pts_linears.%d.bias" % i]).requires_grad_(True); zi.retain_grad()
     z.append(zi); h = torch.relu(zi)
     if i == 4: h = torch.cat([pts, h], -1)
-zs = []
 h7 = h
 alpha = h7 @ W["alpha_linear.weight"].T + W["alpha_linear.bias"]
 f = (h7 @ W["feature_linear.weight"].T + W["feature_linear.bias"]); f.retain_grad()
@@ -36,11 +35,7 @@ zv = (torch.cat([f, views], -1) @ W["views_linears.0.weight"].T + W["views_linea
 hv = torch.relu(zv)
 rgb = hv @ W["rgb_linear.weight"].T + W["rgb_linear.bias"]
 out = torch.cat([rgb, alpha], -1)
-# leaves need grad for retain_grad to work: make the first input require grad
-pts.requires_grad_(False)
-for t in z + [f, zv]:
-    pass
-(out * d_raw).sum().backward() if out.requires_grad else None
+(out * d_raw).sum().backward()
 
 prec = "bf16"
 vd = 1
