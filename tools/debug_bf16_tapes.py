@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, ".")
 from nerf_loc_amd import hip, synth, train      # noqa: E402
 from nerf_loc_amd.helpers import NeRF            # noqa: E402
-from oracle import nerf_oracle as orc            # noqa: E402
+from nerf_loc_amd import helpers                 # noqa: E402
 
 dev = torch.device("cuda:0")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 77
@@ -17,7 +17,8 @@ net = net.to(dev)
 rs = np.random.RandomState(M)
 x = rs.uniform(-3, 3, size=(M, 3)).astype(np.float32)
 d = rs.normal(size=(M, 3)); d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
-feat = torch.from_numpy(np.concatenate([orc.embed(x, 10), orc.embed(d, 4)], -1).astype(np.float32)).to(dev)
+feat = torch.cat([helpers.get_embedder(10, 0)[0](torch.from_numpy(x).to(dev)),
+                  helpers.get_embedder(4, 0)[0](torch.from_numpy(d).to(dev))], -1).contiguous()
 d_raw = torch.from_numpy(rs.randn(M, 4).astype(np.float32)).to(dev)
 
 # float32 torch evaluation with every pre-activation kept
