@@ -97,46 +97,7 @@ cmp("dzv", decode(gt, G, 144, 8), zv.grad)
 cmp("dfeat", decode(gt, G, 128, 16), f.grad)
 for i in range(7, -1, -1):
     cmp("dz%d" % i, decode(gt, G, 16 * i, 16), z[i].grad)
-names = [k for k in train._PARAM_ORDER[True]]
-named = dict(net.named_parameters())
-got = decode(gt, G, 144, 8)[:M]
-ref = zv.grad.cpu().numpy()
 np.set_printoptions(precision=4, suppress=True, linewidth=200)
-print("dzv sample 0 got:", got[0, :24])
-print("dzv sample 0 ref:", ref[0, :24])
-print("dzv sample 40 got:", got[40, :24])
-print("dzv sample 40 ref:", ref[40, :24])
-unm = (d_raw[:, :3] @ W["rgb_linear.weight"]).cpu().numpy()
-print("unmasked ref s0:", unm[0, :24])
-drgb = decode(gt, G, 152, 2)[:M]
-print("drgb tape s0:", drgb[0, :8], "d_raw:", d_raw[0].cpu().numpy())
-print("frac rows where got==0 & ref!=0:", np.mean((got == 0) & (ref != 0)), " got!=0 & ref==0:", np.mean((got != 0) & (ref == 0)))
-hvt = decode(tape, T, 150, 8)          # [Mpad, 128] stored activations
-gz = decode(gt, G, 144, 8)
-unm_full = np.zeros_like(gz); unm_full[:M] = unm
-valid = np.zeros(gz.shape, bool); valid[:64] = np.abs(unm_full[:64]) > 1e-3
-gm = gz != 0
-def score(mask):
-    return float(np.mean(gm[valid] == mask[valid]))
-base_mask = hvt > 0
-print("identity", score(base_mask))
-for sh in (32, 64, 96):
-    print("feature roll", sh, score(np.roll(base_mask, -sh, axis=1)), score(np.roll(base_mask, sh, axis=1)))
-print("half swap", score(base_mask[:, np.arange(128) ^ 16]))
-print("h swap (f^4)", score(base_mask[:, np.arange(128) ^ 4]))
-print("f^8", score(base_mask[:, np.arange(128) ^ 8]))
-idx = np.arange(gz.shape[0])
-print("ct swap", score(base_mask[idx ^ 32]))
-for k in (1, 2, 3):
-    print("qd roll", k, score(base_mask[:, (np.arange(128) & ~3) | ((np.arange(128) + k) & 3)]))
-f_idx = np.arange(128)[None, :].repeat(gz.shape[0], 0)
-s_idx = np.arange(gz.shape[0])[:, None].repeat(128, 1)
-for name, key in (("half", (f_idx >> 4) & 1), ("ct", (s_idx >> 5) & 1), ("hh", (f_idx >> 2) & 1), ("j>>2", (f_idx >> 3) & 1), ("e", f_idx & 3), ("tile", f_idx >> 5)):
-    for v in np.unique(key):
-        sel = valid & (key == v)
-        if sel.any():
-            print(name, v, "identity score %.3f" % float(np.mean(gm[sel] == base_mask[sel])))
 print("alpha bias got", grads[21].cpu().numpy(), "ref sum d_sigma", float(d_raw[:, 3].sum()), "bf16-rounded", float(d_raw[:, 3].bfloat16().float().sum()))
 print("rgb bias got", grads[23].cpu().numpy(), "ref", d_raw[:, :3].sum(0).cpu().numpy())
 print("views bias got[:6]", grads[17].cpu().numpy()[:6], "ref", zv.grad.sum(0).cpu().numpy()[:6])
-print("sum |d_sigma|", float(d_raw[:, 3].abs().sum()))
