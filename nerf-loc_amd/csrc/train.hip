@@ -26,11 +26,18 @@
 namespace nerf {
 
 constexpr int TAPE_PE = 64, TAPE_VW = 32;
-constexpr int tape_floats(bool vd) { return vd ? TAPE_PE + TAPE_VW + 8 * 256 + 256 + 128 : TAPE_PE + 8 * 256; }   // per sample
+// ReLU bits: per sample and ReLU layer (pts_linears.0-7, then views_linears.0) two lane halves x 4 dwords; dword j
+// holds output tiles 2 j (bits 0-15) and 2 j + 1 (bits 16-31), bit e <-> accumulator register e of the tile.  The
+// input-gradient chain reads these instead of the activations.
+constexpr int TAPE_BITS_LAYER = 8;
+constexpr int tape_bits(bool vd) { return (vd ? 9 : 8) * TAPE_BITS_LAYER; }
+constexpr int tape_floats(bool vd) {   // per sample
+    return (vd ? TAPE_PE + TAPE_VW + 8 * 256 + 256 + 128 : TAPE_PE + 8 * 256) + tape_bits(vd);
+}
 constexpr int gtape_floats(bool vd) { return vd ? 8 * 256 + 256 + 128 : 8 * 256; }
 
 struct TapePtrs {
-    float* pe; float* vw; float* h[8]; float* feat; float* hv;
+    float* pe; float* vw; float* h[8]; float* feat; float* hv; unsigned* bits;
 };
 struct GTapePtrs {
     float* dz[8]; float* dfeat; float* dzv;
@@ -49,8 +56,9 @@ static TapePtrs tape_ptrs(float* base, long long M, bool vd) {
     for (int i = 0; i < 8; ++i) { t.h[i] = base + o; o += (size_t)M * 256; }
     if (vd) {
         t.feat = base + o; o += (size_t)M * 256;
-        t.hv = base + o;
+        t.hv = base + o; o += (size_t)M * 128;
     }
+    t.bits = reinterpret_cast<unsigned*>(base + o);
     return t;
 }
 static GTapePtrs gtape_ptrs(float* base, long long M, bool vd) {
@@ -70,38 +78,38 @@ static GTapePtrs gtape_ptrs(float* base, long long M, bool vd) {
 // 16-byte pieces per tile and lane in a sample-major row.
 struct SaveTile {
     float* row;      // dst + m * ld + 4 h (the tapes are padded to whole 128-sample tiles: every lane stores)
+    unsigned* bits;  // 4 dwords of the layer being computed (ReLU layers), or nullptr
     __device__ __forceinline__ void operator()(int t, float (&v)[16]) const {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(row + 32 * t + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        if (bits) {
+            unsigned w = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {   // > 0 on the float's bits as a signed integer: +0 and -0 give 0
+                unsigned b;
+                asm("v_med3_i32 %0, %1, 0, 1" : "=v"(b) : "v"(v[e]));
+                w |= b << e;
+            }
+            bits[t >> 1] = (t & 1) ? (bits[t >> 1] | (w << 16)) : w;
+        }
     }
 };
 
-// gradient tile: zero where the forward activation was not positive (ReLU), then store.  The activation
-// tile is fetched one tile ahead of its use so that its latency hides under the previous tile's MFMAs.
-struct ActTile {
-    float4 q[4];
-};
+// gradient tile: zero where the forward activation was not positive (ReLU bits of the forward tape), then store
+struct ActTile {};
 template <bool MASK>
 struct MaskSaveTile {
-    const float* act;   // forward activation row of the sample (+ 4 h)
-    float* row;         // destination row (+ 4 h)
-    __device__ __forceinline__ ActTile fetch(int t) const {
-        ActTile a;
-        if (MASK) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) a.q[g] = *reinterpret_cast<const float4*>(act + 32 * t + 8 * g);
-        }
-        return a;
-    }
-    __device__ __forceinline__ void apply(int t, float (&v)[16], const ActTile& a) const {
+    const unsigned* bits;   // 4 dwords of the layer (kernel registers), unused without MASK
+    float* row;             // destination row (+ 4 h)
+    __device__ __forceinline__ ActTile fetch(int) const { return ActTile{}; }
+    __device__ __forceinline__ void apply(int t, float (&v)[16], const ActTile&) const {
+        const unsigned w = MASK ? bits[t >> 1] >> (16 * (t & 1)) : 0u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (MASK) {
-                v[4 * g + 0] = a.q[g].x > 0.0f ? v[4 * g + 0] : 0.0f;
-                v[4 * g + 1] = a.q[g].y > 0.0f ? v[4 * g + 1] : 0.0f;
-                v[4 * g + 2] = a.q[g].z > 0.0f ? v[4 * g + 2] : 0.0f;
-                v[4 * g + 3] = a.q[g].w > 0.0f ? v[4 * g + 3] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[4 * g + k] = ((w >> (4 * g + k)) & 1u) ? v[4 * g + k] : 0.0f;
             }
             *reinterpret_cast<float4*>(row + 32 * t + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
         }
@@ -145,20 +153,31 @@ void mlp_f32_train_kernel(MlpArgs a, TapePtrs tp) {
                 for (int g = 0; g < 4; ++g) qv[g] = make_float4(vw[4 * g], vw[4 * g + 1], vw[4 * g + 2], vw[4 * g + 3]);
             }
         }
-        auto save256 = [&](float* base) { return SaveTile{base + (size_t)m * 256 + 4 * h}; };
+        unsigned lb[4];                     // ReLU bits of the layer in progress
+        auto save256 = [&](float* base, bool relu = true) { return SaveTile{base + (size_t)m * 256 + 4 * h, relu ? lb : nullptr}; };
+        uint4* brow = reinterpret_cast<uint4*>(tp.bits + (size_t)m * tape_bits(VD)) + h;     // + 2 per layer
+        auto flush_bits = [&](int layer) { brow[2 * layer] = make_uint4(lb[0], lb[1], lb[2], lb[3]); };
 
         float A[8][16], B[8][16];
         int pos = 0, bt = 0;
         layer_f32<8, true, 0, false, true>(p, pos, bt, h, pe, A, vw, A, save256(tp.h[0]));
+        flush_bits(0);
         layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, A, vw, B, save256(tp.h[1]));
+        flush_bits(1);
         layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, B, vw, A, save256(tp.h[2]));
+        flush_bits(2);
         layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, A, vw, B, save256(tp.h[3]));
+        flush_bits(3);
         layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, B, vw, A, save256(tp.h[4]));
+        flush_bits(4);
         layer_f32<8, true, 8, false, true>(p, pos, bt, h, pe, A, vw, B, save256(tp.h[5]));
+        flush_bits(5);
         layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, B, vw, A, save256(tp.h[6]));
+        flush_bits(6);
         layer_f32<8, false, 8, false, true>(p, pos, bt, h, pe, A, vw, B, save256(tp.h[7]));
+        flush_bits(7);
         if (VD) {
-            layer_f32<8, false, 8, false, false>(p, pos, bt, h, pe, B, vw, A, save256(tp.feat));
+            layer_f32<8, false, 8, false, false>(p, pos, bt, h, pe, B, vw, A, save256(tp.feat, false));
             float o3;
             {
                 f32x16 acc = bias_tile(p.lds, bt, h);
@@ -166,7 +185,9 @@ void mlp_f32_train_kernel(MlpArgs a, TapePtrs tp) {
                 pos += 32; bt += 1;
                 o3 = acc[3];
             }
-            layer_f32<4, false, 8, true, true>(p, pos, bt, h, pe, A, vw, B, SaveTile{tp.hv + (size_t)m * 128 + 4 * h});
+            lb[2] = lb[3] = 0u;
+            layer_f32<4, false, 8, true, true>(p, pos, bt, h, pe, A, vw, B, SaveTile{tp.hv + (size_t)m * 128 + 4 * h, lb});
+            flush_bits(8);
             f32x16 acc = bias_tile(p.lds, bt, h);
             mma_run_f32<16>(p, pos, acc, &B[0][0]);
             if (valid && h == 0) *reinterpret_cast<float4*>(a.out + (size_t)m * 4) = make_float4(acc[0], acc[1], acc[2], o3);
@@ -245,30 +266,41 @@ void mlp_dgrad_f32_kernel(DgradArgs a) {
 #pragma unroll
         for (int k = 0; k < OUT_CH; ++k) dr[k] = drp[k];
         const float none[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        auto rows = [&](const float* act, float* dst, int ld) {
-            return MaskSaveTile<true>{act + (size_t)m * ld + 4 * h, dst + (size_t)m * ld + 4 * h};
+        // ReLU bits of all layers of the pass: no load is left inside the layer loop, where the wait for it would
+        // also wait for the gradient-tape stores issued before it
+        unsigned lb[VD ? 9 : 8][4];
+        {
+            const uint4* brow = reinterpret_cast<const uint4*>(a.tp.bits + (size_t)m * tape_bits(VD)) + h;
+#pragma unroll
+            for (int l = 0; l < (VD ? 9 : 8); ++l) {
+                const uint4 q = brow[2 * l];
+                lb[l][0] = q.x; lb[l][1] = q.y; lb[l][2] = q.z; lb[l][3] = q.w;
+            }
+        }
+        auto rows = [&](int layer, float* dst, int ld) {
+            return MaskSaveTile<true>{lb[layer], dst + (size_t)m * ld + 4 * h};
         };
         float A[8][16], B[8][16];
         int pos = 0;
         if (VD) {
             const float drgb[4] = {h ? 0.0f : dr[0], h ? 0.0f : dr[1], h ? 0.0f : dr[2], 0.0f};
             const float dsig[4] = {h ? 0.0f : dr[3], 0.0f, 0.0f, 0.0f};
-            layer_bwd_f32<4, 1, false>(p, pos, &drgb[0], none, B, rows(a.tp.hv, a.gt.dzv, 128));
+            layer_bwd_f32<4, 1, false>(p, pos, &drgb[0], none, B, rows(8, a.gt.dzv, 128));
             layer_bwd_f32<8, 16, false>(p, pos, &B[0][0], none, A,
                                         MaskSaveTile<false>{nullptr, a.gt.dfeat + (size_t)m * 256 + 4 * h});
-            layer_bwd_f32<8, 32, true>(p, pos, &A[0][0], dsig, B, rows(a.tp.h[7], a.gt.dz[7], 256));
+            layer_bwd_f32<8, 32, true>(p, pos, &A[0][0], dsig, B, rows(7, a.gt.dz[7], 256));
         } else {
             const float dout[4] = {h ? (OUT_CH > 4 ? dr[OUT_CH > 4 ? 4 : 0] : 0.0f) : dr[0], h ? 0.0f : dr[1], h ? 0.0f : dr[2],
                                    h ? 0.0f : dr[3]};
-            layer_bwd_f32<8, 1, false>(p, pos, &dout[0], none, B, rows(a.tp.h[7], a.gt.dz[7], 256));
+            layer_bwd_f32<8, 1, false>(p, pos, &dout[0], none, B, rows(7, a.gt.dz[7], 256));
         }
-        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[6], a.gt.dz[6], 256));   // pts_linears.7^T
-        layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(a.tp.h[5], a.gt.dz[5], 256));   // .6
-        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[4], a.gt.dz[4], 256));   // .5 (hidden columns)
-        layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(a.tp.h[3], a.gt.dz[3], 256));   // .4
-        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[2], a.gt.dz[2], 256));   // .3
-        layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(a.tp.h[1], a.gt.dz[1], 256));   // .2
-        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(a.tp.h[0], a.gt.dz[0], 256));   // .1
+        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(6, a.gt.dz[6], 256));   // pts_linears.7^T
+        layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(5, a.gt.dz[5], 256));   // .6
+        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(4, a.gt.dz[4], 256));   // .5 (hidden columns)
+        layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(3, a.gt.dz[3], 256));   // .4
+        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(2, a.gt.dz[2], 256));   // .3
+        layer_bwd_f32<8, 32, false>(p, pos, &A[0][0], none, B, rows(1, a.gt.dz[1], 256));   // .2
+        layer_bwd_f32<8, 32, false>(p, pos, &B[0][0], none, A, rows(0, a.gt.dz[0], 256));   // .1
         // zero fragments that pad the stream to a whole stage
 #pragma unroll
         for (int g = 0; g < pad_to_stage(VD ? FRAGS_BWD_F32_VD : FRAGS_BWD_F32_NOVD) - (VD ? FRAGS_BWD_F32_VD : FRAGS_BWD_F32_NOVD); ++g)

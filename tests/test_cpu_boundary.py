@@ -102,8 +102,10 @@ def test_training_entry_points_check_precision_and_sizes():
     """Host-only checks of the training side of the ABI: tape sizes per precision, unknown precisions refused."""
     lib = hip.lib()
     f32, b16 = hip.PREC_F32, hip.PREC_BF16
-    # float32 tapes: sample-major rows padded to 128 samples (pe 64 + view 32 + 8 x 256 + 256 + 128 floats)
-    assert lib.nerf_train_tape_bytes(1, 1, f32) == 128 * (64 + 32 + 8 * 256 + 256 + 128) * 4
+    # float32 tapes: sample-major rows padded to 128 samples (pe 64 + view 32 + 8 x 256 + 256 + 128 floats, then
+    # 8 dwords of ReLU bits per ReLU layer)
+    assert lib.nerf_train_tape_bytes(1, 1, f32) == 128 * (64 + 32 + 8 * 256 + 256 + 128 + 9 * 8) * 4
+    assert lib.nerf_train_tape_bytes(129, 0, f32) == 256 * (64 + 8 * 256 + 8 * 8) * 4
     assert lib.nerf_train_grad_tape_bytes(1, 1, f32) == 128 * (8 * 256 + 256 + 128) * 4
     # bf16 tapes: 2 KiB operand pieces per 64 samples, padded to 256 samples (167 / 156 with view directions)
     assert lib.nerf_train_tape_bytes(1, 1, b16) == 4 * 167 * 2048
