@@ -40,6 +40,8 @@ extern "C" {
 #define NERF_IN_RAYS 2        /* in0 = rays [R, ray_cols], in1 = z_vals [R, S]: pts = o + d*z made */
                               /* in registers, never written to memory (render_rays)               */
 
+/* Version of this interface (2: the training entry points take a `precision` argument). */
+#define NERF_HIP_ABI_VERSION 2
 int nerf_hip_abi_version(void);
 const char* nerf_last_error(void);
 

@@ -17,5 +17,5 @@ void set_error(const char* fmt, ...) {
 
 }  // namespace nerf
 
-extern "C" int nerf_hip_abi_version(void) { return 1; }
+extern "C" int nerf_hip_abi_version(void) { return NERF_HIP_ABI_VERSION; }
 extern "C" const char* nerf_last_error(void) { return nerf::g_err; }

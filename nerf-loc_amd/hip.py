@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "lib", "libnerf_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
+ABI_VERSION = 2      # 2: the training entry points take a precision argument
 IN_FEATURES, IN_POINTS, IN_RAYS = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
 
@@ -95,6 +96,9 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        if L.nerf_hip_abi_version() != ABI_VERSION:
+            raise NerfHipError("%s has ABI version %d, this binding needs %d: rebuild it with `make -C nerf-loc_amd/csrc`"
+                               % (LIB_PATH, L.nerf_hip_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

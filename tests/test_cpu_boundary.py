@@ -69,7 +69,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in _header_decls():
         assert hasattr(L, name), "libnerf_hip.so does not export %s" % name
     lib = hip.lib()
-    assert lib.nerf_hip_abi_version() == 1
+    assert lib.nerf_hip_abi_version() == hip.ABI_VERSION == 2
     assert lib.nerf_last_error() is not None
 
 
