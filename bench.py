@@ -11,7 +11,14 @@ N > 1 every rank renders its own 640 000-ray shard of an N x 640 000-ray batch (
 all-gather assembles the per-ray maps on every rank inside the timed region.
 
 Rank 0 prints ONE JSON line: rays/s over all ranks, the MFMA roofline of the network kernel (HIP events
-around every launch of it in the timed region) and the CPU oracle timed on a bounded sample.
+around every launch of it in the timed region) and the CPU oracle timed on a bounded sample.  The same line also
+carries, measured after the headline region in the same process: "fp32" (the same view in the exact-float32 MFMA
+mode, the precision the reference computes in) and "strong_4m" (BASELINE configs[2]: 4 194 304 rays split over
+the ranks, one all-gather).
+
+Launching: under torchrun (WORLD_SIZE set) every process is one rank and --gpus must equal WORLD_SIZE.  Without
+it, `bench.py --gpus N` with N > 1 starts N rank processes itself (the parent never touches a GPU), relays rank
+0's line and exits non-zero if any rank fails.
 """
 import argparse
 import json
@@ -71,8 +78,26 @@ def cpu_baseline(seconds_target=12.0):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
-    return {"value": n2 / dt, "unit": "rays/s", "cores": int(cores), "kind": "port",
-            "sample": "first %d rays of the same 800x800 view, 64+128 samples, numpy oracle (float32, BLAS threads)" % n2}
+    # the reference's own CPU-runnable case beside it (BASELINE configs[0]: coarse pass only, 64 samples), bounded too
+    n3 = n2 * 3
+    t0 = time.time()
+    orc.render_rays(rays[:n3], sc, 64, 0, white_bkgd=True)
+    dt3 = time.time() - t0
+    return {"value": n2 / dt, "unit": "rays/s", "cores": int(cores), "kind": "port", "cpu": cpu_model(),
+            "sample": "first %d rays of the same 800x800 view, 64+128 samples, numpy oracle (float32, BLAS threads)" % n2,
+            "coarse_only": {"value": n3 / dt3, "unit": "rays/s",
+                            "sample": "first %d rays of the same view, 64 coarse samples only" % n3}}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def pmc_traffic(precision):
@@ -112,7 +137,7 @@ def build_objects(device, precision, n_objects):
     return objs, H, W, K, Kc, poses
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -123,55 +148,97 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--chunk", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="view workload: skip the fp32 and 4M-ray legs that follow the headline region")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only: every rank joins the process group, rank 0 prints the world it sees; no "
+                         "GPU work (checks the launcher, also on a machine without GPUs)")
     ap.add_argument("--workload", default="view", choices=["view", "rays4m", "objects", "train"],
                     help="view: BASELINE configs[1] (default, the headline line); rays4m: configs[2], a 4 194 304-ray "
                          "batch split over the ranks; objects: configs[3], per-object networks dealt to the ranks; "
                          "train: configs[4], 4096-ray training iteration, data parallel")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    from nerf_loc_amd import dist as ndist, hip, render, synth
-    import torch.distributed as tdist
-    rank, world, device = ndist.init_from_env()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    hip.lib()
-    keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
-    scaling = "weak"
-    flop_per_ray = 256 * FLOP_PER_SAMPLE
-    if args.workload in ("view", "rays4m"):
-        H, W, K, c2w, kwargs = build_scene(device, args.precision, args.res)
+
+def resolve_world(gpus, environ):
+    """('rank', world) when this process is one rank of a job somebody else started (WORLD_SIZE set: --gpus must
+    agree with it), ('launch', N) when it has to start N ranks itself, ('rank', 1) for a plain single-GPU run."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1, got %d" % gpus)
+    ws = environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s; they must agree" % (gpus, ws))
+        return "rank", int(ws)
+    return ("launch", gpus) if gpus > 1 else ("rank", 1)
+
+
+def launch_ranks(n, argv):
+    """Start n rank processes of this script (one per GPU, rendezvous on 127.0.0.1), relay rank 0's output and
+    return non-zero if any rank failed.  Nothing here initialises a GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode("utf-8", "replace")
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        return 1
+    return 0
+
+
+KEYS = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
+
+
+def make_workload(name, precision, args, rank, world, device):
+    """-> dict(step, n_rays (this rank), total_rays (all ranks, per step), desc, scaling, flop_per_ray, parallelism)."""
+    from nerf_loc_amd import dist as ndist, render, synth
+    w = {"scaling": "weak", "flop_per_ray": 256 * FLOP_PER_SAMPLE, "precision": precision}
+    if name in ("view", "rays4m"):
+        H, W, K, c2w, kwargs = build_scene(device, precision, args.res)
         rk = {k: v for k, v in kwargs.items() if k not in ("near", "far", "use_viewdirs", "ndc")}
-    if args.workload == "view":
-        n_rays = H * W                      # per rank
-        total_rays = n_rays * world
-        desc = ("BASELINE configs[1]: %dx%d view (%d rays/GPU), 64 coarse + 128 importance samples, D8/W256 L10/4 "
-                "viewdirs, separate fine net, seeded random weights, %s-MFMA mode" % (H, W, n_rays, args.precision))
+        w["parallelism"] = "ray-shard x%d + 1 all-gather" % world
+    if name == "view":
+        n_rays = H * W
+        w.update(n_rays=n_rays, total_rays=n_rays * world,
+                 desc=("BASELINE configs[1]: %dx%d view (%d rays/GPU), 64 coarse + 128 importance samples, D8/W256 L10/4 "
+                       "viewdirs, separate fine net, seeded random weights, %s-MFMA mode" % (H, W, n_rays, precision)))
 
         def step():
             rays_flat, _ = render._build_rays(H, W, K, None, c2w, False, kwargs["near"], kwargs["far"], True, None)
-            rec = ndist.pack_record(render.batchify_rays(rays_flat, args.chunk, **rk), keys)
+            rec = ndist.pack_record(render.batchify_rays(rays_flat, args.chunk, **rk), KEYS)
             return ndist.all_gather_rows(rec, n_rays * world, n_rays) if world > 1 else rec
-    elif args.workload == "rays4m":
-        scaling = "strong"
+    elif name == "rays4m":
         total_rays = 4194304
         all_rays = torch.from_numpy(synth.random_rays(total_rays, seed=0)).to(device)
         lo, hi, per = ndist.shard_bounds(total_rays, rank, world)
-        n_rays = hi - lo
-        desc = ("BASELINE configs[2]: 4 194 304 synthetic rays split over %d GPU(s), 64 + 128 samples, %s-MFMA mode, "
-                "one all-gather of the per-ray record" % (world, args.precision))
+        w.update(scaling="strong", n_rays=hi - lo, total_rays=total_rays,
+                 desc=("BASELINE configs[2]: 4 194 304 synthetic rays split over %d GPU(s), 64 + 128 samples, %s-MFMA "
+                       "mode, one all-gather of the per-ray record" % (world, precision)))
 
         def step():
-            rec = ndist.pack_record(render.batchify_rays(all_rays[lo:hi], args.chunk, **rk), keys)
+            rec = ndist.pack_record(render.batchify_rays(all_rays[lo:hi], args.chunk, **rk), KEYS)
             return ndist.all_gather_rows(rec, total_rays, per) if world > 1 else rec
-    elif args.workload == "objects":
+    elif name == "objects":
         from nerf_loc_amd import nerf_utils
         n_obj = 8                           # per rank (weak scaling: 64 objects on 8 GPUs)
-        objs, H, W, K, Kc, poses = build_objects(device, args.precision, n_obj)
+        objs, H, W, K, Kc, poses = build_objects(device, precision, n_obj)
         n_rays = n_obj * 2 * 8 * H * W
-        total_rays = n_rays * world
-        flop_per_ray = 64 * FLOP_PER_SAMPLE
-        desc = ("BASELINE configs[3]: %d objects/GPU x 2 focal lengths x 8 poses x %dx%d, 64 samples, coarse net, "
-                "rgb + depth + raw volume kept on device, %s-MFMA mode" % (n_obj, H, W, args.precision))
+        w.update(n_rays=n_rays, total_rays=n_rays * world, flop_per_ray=64 * FLOP_PER_SAMPLE,
+                 parallelism="objects round-robin x%d, no collective" % world,
+                 desc=("BASELINE configs[3]: %d objects/GPU x 2 focal lengths x 8 poses x %dx%d, 64 samples, coarse net, "
+                       "rgb + depth + raw volume kept on device, %s-MFMA mode" % (n_obj, H, W, precision)))
 
         def step():
             out = None
@@ -183,10 +250,6 @@ def main():
     else:
         from nerf_loc_amd import helpers, train
         total = 4096
-        n_rays = total // world
-        total_rays = total
-        scaling = "strong"
-        flop_per_ray = 3 * 256 * FLOP_PER_SAMPLE
         H, W, K, c2w, kwargs = build_scene(device, "fp32", 64)
         for k in ("network_fn", "network_fine"):
             kwargs[k].requires_grad_(True)
@@ -198,11 +261,13 @@ def main():
         tgt_all = torch.rand(total, 3, generator=torch.Generator().manual_seed(0)).to(device)
         lo, hi, _ = ndist.shard_bounds(total, rank, world)
         rays_l, tgt_l = rays_all[lo:hi], tgt_all[lo:hi]
-        args.precision = args.train_precision
         train.set_train_precision(args.train_precision)
-        desc = ("BASELINE configs[4]: training iteration, 4096 rays over %d GPU(s), 64 + 128 samples, stratified "
-                "jitter, forward + backward of both networks + one gradient all-reduce + Adam, %s"
-                % (world, "float32" if args.train_precision == "fp32" else "bf16 operands, float32 accumulation and parameters"))
+        w.update(scaling="strong", n_rays=hi - lo, total_rays=total, flop_per_ray=3 * 256 * FLOP_PER_SAMPLE,
+                 precision=args.train_precision, parallelism="data parallel x%d, 1 gradient all-reduce" % world,
+                 desc=("BASELINE configs[4]: training iteration, 4096 rays over %d GPU(s), 64 + 128 samples, stratified "
+                       "jitter, forward + backward of both networks + one gradient all-reduce + Adam, %s"
+                       % (world, "float32" if args.train_precision == "fp32" else
+                          "bf16 operands, float32 accumulation and parameters")))
         it = [0]
 
         def step():
@@ -210,24 +275,33 @@ def main():
             opt.zero_grad()
             loss = helpers.img2mse(ret["rgb_map"], tgt_l) + helpers.img2mse(ret["rgb0"], tgt_l)
             loss.backward()
-            ndist.average_gradients([kwargs["network_fn"], kwargs["network_fine"]])
+            ndist.average_gradients([kwargs["network_fn"], kwargs["network_fine"]], n_local=hi - lo, n_global=total)
             opt.step()
             it[0] += 1
             for g in opt.param_groups:
                 g["lr"] = 5e-4 * (0.1 ** (it[0] / 500000.0))
             return ret["rgb_map"].detach()
+    w["step"] = step
+    return w
+
+
+def timed(step, steps, warmup, world, device):
+    """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; the time is
+    the maximum over ranks.  Returns (seconds, HIP-event records of the network launches, last output)."""
+    import torch.distributed as tdist
+    from nerf_loc_amd import hip
 
     def sync():
         if world > 1:
             tdist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync()
     hip.MLP_EVENTS = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
     sync()
     dt = time.perf_counter() - t0
@@ -237,27 +311,87 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out[:, :3]).all()
+    return dt, events, out
+
+
+def mlp_roofline(events, precision, dt, n_rays, traffic):
+    """MFMA roofline of the network kernel from the HIP events of its launches: the largest launches (the fine pass)
+    carry `achieved`; algorithmic FLOPs = samples x 1 186 816."""
+    peak = PEAK_TFLOPS[precision]
+    kname = "mlp_%s_kernel" % ("bf16" if precision == "bf16" else "f32")
+    ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+    flops = [n * FLOP_PER_SAMPLE for _, _, n in events]
+    big = [(m, f) for m, f in zip(ms, flops) if f == max(flops)]
+    ach = sum(f for _, f in big) / (sum(m for m, _ in big) * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+            "traffic_unit": "HBM-side bytes per largest launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate "
+                            "PMC passes of the default command)",
+            "algorithmic_bytes": big[0][1] // FLOP_PER_SAMPLE * 20 + n_rays * 44,
+            "kernel": "%s (largest launches: %d samples each, avg %.3f ms)"
+                      % (kname, big[0][1] // FLOP_PER_SAMPLE, sum(m for m, _ in big) / len(big)),
+            "all_launches_tflops": sum(flops) / (sum(ms) * 1e-3) / 1e12,
+            "mlp_time_share": sum(ms) * 1e-3 / dt}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    mode, n = resolve_world(args.gpus, os.environ)
+    if mode == "launch":
+        raise SystemExit(launch_ranks(n, argv))
+
+    from nerf_loc_amd import dist as ndist, hip
+    import torch.distributed as tdist
+    if args.dry_run:
+        rank, world, _ = ndist.init_from_env(None if os.environ.get("NERF_DIST_BACKEND") else "gloo")
+        if world > 1:
+            t = torch.ones(1)
+            tdist.all_reduce(t)
+            assert int(t.item()) == world
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": tdist.get_world_size() if world > 1 else 1,
+                              "backend": tdist.get_backend() if world > 1 else "none", "gpus_arg": args.gpus}))
+        if world > 1:
+            tdist.barrier()
+            tdist.destroy_process_group()
+        return
+    rank, world, device = ndist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    hip.lib()
+    backend = tdist.get_backend() if world > 1 else "none"
+    precision = args.precision
+    w = make_workload(args.workload, precision, args, rank, world, device)
+    precision = w["precision"]
+    dt, events, _ = timed(w["step"], args.steps, args.warmup, world, device)
+    n_rays, total_rays = w["n_rays"], w["total_rays"]
+    meta = {k: v for k, v in w.items() if k != "step"}
+
+    extras = {}
+    if args.workload == "view" and not args.no_extras:
+        # the same view in the reference's own precision, and the 4M-ray strong-scaling batch, in this same run
+        w = None      # drops the closure and with it the headline workload's device tensors
+        torch.cuda.empty_cache()
+        for tag, wl, prec, st, wu in (("fp32", "view", "fp32", 2, 1), ("strong_4m", "rays4m", "bf16", 2, 1)):
+            if tag == "fp32" and precision == "fp32":
+                continue
+            x = make_workload(wl, prec, args, rank, world, device)
+            dtx, evx, _ = timed(x["step"], st, wu, world, device)
+            extras[tag] = {"value": x["total_rays"] * st / dtx, "unit": "rays/s", "ms_per_step": dtx / st * 1e3,
+                           "steps": st, "warmup": wu, "dtype": "f32" if prec == "fp32" else "bf16",
+                           "scaling": x["scaling"], "rays_per_gpu": x["n_rays"], "workload": x["desc"],
+                           "roofline": mlp_roofline(evx, prec, dtx, x["n_rays"],
+                                                    pmc_traffic(prec) if wl == "view" else None)}
+            del x
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        peak = PEAK_TFLOPS[args.precision]
-        kname = "mlp_%s_kernel" % ("bf16" if args.precision == "bf16" else "f32")
+        peak = PEAK_TFLOPS[precision]
         if events:
-            ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
-            flops = [n * FLOP_PER_SAMPLE for _, _, n in events]
-            big = [(m, f) for m, f in zip(ms, flops) if f == max(flops)]
-            ach = sum(f for _, f in big) / (sum(m for m, _ in big) * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                    "traffic": pmc_traffic(args.precision) if args.workload == "view" else None,
-                    "traffic_unit": "HBM-side bytes per largest launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate "
-                                    "PMC passes of the default command)",
-                    "algorithmic_bytes": big[0][1] // FLOP_PER_SAMPLE * 20 + n_rays * 44,
-                    "kernel": "%s (largest launches: %d samples each, avg %.3f ms)"
-                              % (kname, big[0][1] // FLOP_PER_SAMPLE, sum(m for m, _ in big) / len(big)),
-                    "all_launches_tflops": sum(flops) / (sum(ms) * 1e-3) / 1e12,
-                    "mlp_time_share": sum(ms) * 1e-3 / dt}
+            roof = mlp_roofline(events, precision, dt, n_rays, pmc_traffic(precision) if args.workload == "view" else None)
         else:   # training: forward-with-tape, input-gradient and weight-gradient kernels, timed as a whole step
-            ach = n_rays * flop_per_ray * args.steps / dt / 1e12
-            if args.precision == "bf16":
+            ach = n_rays * meta["flop_per_ray"] * args.steps / dt / 1e12
+            if precision == "bf16":
                 # tape traffic per sample: forward writes 167 pieces of 32 B (9 of them ReLU bits), the input-gradient
                 # chain reads those 9 and writes 156, the weight-gradient launches read 156 (gradients) + 178 (inputs)
                 tape_bytes = (167 + 9 + 156 + 156 + 178) * 32
@@ -266,22 +400,24 @@ def main():
                         "kernel": "whole iteration (mlp_bf16_kernel<TAPE> + mlp_dgrad_bf16_kernel + wgrad16_kernel): "
                                   "%d B of tape traffic per sample / step time; %.0f TFLOP/s at 3 x forward FLOPs" % (tape_bytes, ach)}
             else:
-              roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                      "kernel": "whole iteration (mlp_f32_train_kernel + mlp_dgrad_f32_kernel + wgrad_kernel), "
-                                "3 x forward FLOPs per sample / step time"}
+                roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                        "kernel": "whole iteration (mlp_f32_train_kernel + mlp_dgrad_f32_kernel + wgrad_kernel), "
+                                  "3 x forward FLOPs per sample / step time"}
+        metric = {"view": "rendered rays/sec (64+128 samples)", "rays4m": "rendered rays/sec (64+128 samples)",
+                  "objects": "rendered rays/sec (64 samples, coarse only)",
+                  "train": "training rays/sec (64+128 samples, fwd+bwd+Adam)"}[args.workload]
         line = {
-            "metric": "rendered rays/sec (64+128 samples)" if args.workload in ("view", "rays4m") else
-                      ("rendered rays/sec (64 samples, coarse only)" if args.workload == "objects" else "training rays/sec (64+128 samples, fwd+bwd+Adam)"),
+            "metric": metric,
             "value": total_rays * args.steps / dt, "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": desc, "rays_per_gpu": n_rays, "chunk": args.chunk,
-                       "parallelism": "ray-shard x%d + 1 all-gather" % world if args.workload in ("view", "rays4m") else
-                                      ("objects round-robin x%d, no collective" % world if args.workload == "objects"
-                                       else "data parallel x%d, 1 gradient all-reduce" % world)},
+            "n_gpus": world, "backend": backend, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": meta["scaling"], "vs_baseline": None,
+            "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": meta["desc"], "rays_per_gpu": n_rays, "chunk": args.chunk,
+                       "parallelism": meta["parallelism"]},
             "roofline": roof,
         }
+        line.update(extras)
         # the CPU figure is reported once, by the single-GPU run
         line["cpu_baseline"] = None if (args.no_cpu_baseline or args.workload != "view" or world > 1) else cpu_baseline()
         print(json.dumps(line))

@@ -548,15 +548,18 @@ extern "C" int nerf_debug_read_stamps(unsigned long long* host_out) {
 }
 #endif
 
+// mismatch counter of the self test: a device global, so the test allocates nothing.  Host code reaches it only
+// through the address hipGetSymbolAddress returns for the current device.
+__device__ int g_selftest_bad;
+
 extern "C" int nerf_selftest_mfma(void) {
     int* d = nullptr;
-    NERF_HIP_CHECK(hipMalloc(&d, sizeof(int)));
+    NERF_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&d), HIP_SYMBOL(g_selftest_bad)));
     NERF_HIP_CHECK(hipMemset(d, 0, sizeof(int)));
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, 0, d);
     NERF_LAUNCH_CHECK();
     int hbad = -1;
     NERF_HIP_CHECK(hipMemcpy(&hbad, d, sizeof(int), hipMemcpyDeviceToHost));
-    NERF_HIP_CHECK(hipFree(d));
     if (hbad != 0) {
         set_error("MFMA lane-map self test: %d mismatching accumulator elements", hbad);
         return NERF_E_HIP;

@@ -331,16 +331,18 @@ struct PackArgs {
 };
 int launch_pack(const PackArgs& a, hipStream_t stream);
 
+// compute units of the CURRENT device (a process may drive several GPUs: cached per device id)
 static inline int cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
+    constexpr int MAX_DEV = 64;
+    static int n[MAX_DEV] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 256;
+    if (n[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n[dev] = v;
     }
-    return n;
+    return n[dev];
 }
 
 

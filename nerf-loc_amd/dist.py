@@ -116,28 +116,38 @@ def render_rays_sharded(rays_flat, render_fn, keys=None):
     return unpack_record(all_gather_rows(rec, n, per), keys)
 
 
-def average_gradients(modules):
+def average_gradients(modules, n_local=None, n_global=None):
     """Data-parallel step between backward() and optimizer.step(): ONE all-reduce (sum) over the
-    concatenated gradients of all given modules (coarse + fine network: 1 191 688 floats, 4.8 MB),
-    divided by the world size.  Every rank computes the loss as a mean over ITS rays, so the average of
-    the per-rank gradients is the gradient of the mean over the global batch (equal shard sizes), and
-    identical Adam states then stay identical on every rank."""
+    concatenated gradients of all given modules (coarse + fine network: 1 191 688 floats, 4.8 MB).
+    Every rank computes its loss as a mean over ITS n_local rays; the gradient of the mean over the global batch
+    of n_global rays is sum_r (n_local_r / n_global) grad_r, so each rank scales by its own weight before the sum.
+    Without the counts the shards are taken to be equal (weight 1 / world size).  The buffer covers every
+    parameter that requires grad, in module order, with zeros where a rank has no gradient (an empty shard), so
+    all ranks reduce the same length; afterwards every such parameter carries the global gradient, and identical
+    Adam states stay identical on every rank."""
     g = world()
-    params = [p for m in modules for p in m.parameters() if p.grad is not None]
+    params = [p for m in modules for p in m.parameters() if p.requires_grad]
     if g == 1 or not params:
         return 0
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    if (n_local is None) != (n_global is None):
+        raise ValueError("average_gradients: pass both n_local and n_global, or neither")
+    weight = 1.0 / g if n_local is None else float(n_local) / float(n_global)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    if weight != 1.0:
+        flat = flat * weight
     if flat.is_cuda and dist.get_backend() == "gloo":
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
         flat = host.to(flat.device)
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= g
     o = 0
     for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        n = p.numel()
+        if p.grad is None:
+            p.grad = flat[o:o + n].view_as(p).clone()
+        else:
+            p.grad.copy_(flat[o:o + n].view_as(p.grad))
         o += n
     return o
 

@@ -218,9 +218,7 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
     """run_nerf_helpers.py:175-192 on device tensors of shape [..., 3]."""
     sh = rays_d.shape
     K = [[focal, 0, 0], [0, focal, 0], [0, 0, 1]]
-    if float(near) != 1.0:
-        raise NotImplementedError("ndc_rays: the reference only ever passes near=1.0 (run_nerf.py:114)")
-    r = hip.make_rays(H, W, K, rays_o=rays_o, rays_d=rays_d, use_viewdirs=False, ndc=True)
+    r = hip.make_rays(H, W, K, rays_o=rays_o, rays_d=rays_d, use_viewdirs=False, ndc=True, ndc_near=float(near))
     return r[:, 0:3].reshape(sh), r[:, 3:6].reshape(sh)
 
 

@@ -135,8 +135,9 @@ def selftest():
 
 # --------------------------------------------------------------------------- rays
 def make_rays(H, W, K, c2w=None, rays_o=None, rays_d=None, near=0.0, far=1.0, use_viewdirs=False, ndc=False,
-              c2w_view=None, device=None):
-    """[N, 8|11] ray batch from a pose (pixel grid) or from given origins/directions."""
+              c2w_view=None, device=None, ndc_near=1.0):
+    """[N, 8|11] ray batch from a pose (pixel grid) or from given origins/directions.  ndc_near is the near plane
+    of the NDC warp (ndc_rays' `near`; render() always passes 1.0, run_nerf.py:114)."""
     fx, fy, cx, cy = float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
     near_arr = far_arr = None
     if isinstance(near, torch.Tensor):
@@ -158,7 +159,7 @@ def make_rays(H, W, K, c2w=None, rays_o=None, rays_d=None, near=0.0, far=1.0, us
     with torch.cuda.device(dev):
         _check(lib().nerf_make_rays(n, int(H), int(W), _ptr(o_in), _ptr(d_in), _ptr(c2w) if rays_o is None else None,
                                     _ptr(cv), fx, fy, cx, cy, float(near), float(far), _ptr(near_arr), _ptr(far_arr),
-                                    int(bool(use_viewdirs)), int(bool(ndc)), fx, 1.0, _ptr(out), _stream(out)),
+                                    int(bool(use_viewdirs)), int(bool(ndc)), fx, float(ndc_near), _ptr(out), _stream(out)),
                "nerf_make_rays")
     return out
 
@@ -366,6 +367,8 @@ def mlp_backward(packed_bwd, use_viewdirs, output_ch, d_raw, tape, shapes, preci
     dev = d_raw.device
     M = d_raw.numel() // output_ch
     vd = int(bool(use_viewdirs))
+    if M == 0:      # an empty shard of a data-parallel batch: zero gradients, so the all-reduce still lines up
+        return [None if s is None else torch.zeros(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
     gtape = torch.empty((lib().nerf_train_grad_tape_bytes(M, vd, prec) // 4,), dtype=torch.float32, device=dev)
     ws = _WORKSPACE.get(str(dev))
     if ws is None:

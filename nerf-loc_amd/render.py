@@ -215,17 +215,28 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
 
 def _build_rays(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam):
     """Ray source selection, view directions, NDC and [N, 8|11] packing of
-    run_nerf.py:95-123 in one kernel.  Returns (rays_flat, leading shape)."""
+    run_nerf.py:95-123 in one kernel.  Returns (rays_flat, leading shape).
+    c2w_staticcam is consulted only with use_viewdirs, like the reference (run_nerf.py:102-107): geometry then
+    comes from the static camera's H x W grid and the view directions from c2w or from the given rays."""
+    static = c2w_staticcam if use_viewdirs else None
     if c2w is not None:
         c2w = torch.as_tensor(c2w)
-        if c2w_staticcam is not None:
-            # view directions from c2w, geometry from the static camera (run_nerf.py:104-107)
-            flat = hip.make_rays(H, W, K, c2w=torch.as_tensor(c2w_staticcam).to(c2w.device), near=near, far=far,
-                                 use_viewdirs=use_viewdirs, ndc=ndc, c2w_view=c2w if use_viewdirs else None)
+        if static is not None:
+            flat = hip.make_rays(H, W, K, c2w=torch.as_tensor(static).to(c2w.device), near=near, far=far,
+                                 use_viewdirs=True, ndc=ndc, c2w_view=c2w)
         else:
             flat = hip.make_rays(H, W, K, c2w=c2w, near=near, far=far, use_viewdirs=use_viewdirs, ndc=ndc)
         return flat, [H, W]
     rays_o, rays_d = rays
+    if static is not None:
+        # the reference concatenates the static camera's H*W rays with the N given view directions: N must be H*W
+        n = rays_d.reshape(-1, 3).shape[0]
+        if n != H * W:
+            raise ValueError("c2w_staticcam with a ray batch needs H*W = %d rays, got %d" % (H * W, n))
+        view = hip.make_rays(H, W, K, rays_o=rays_o.float(), rays_d=rays_d.float(), use_viewdirs=True)[:, 8:11]
+        geom = hip.make_rays(H, W, K, c2w=torch.as_tensor(static).to(view.device), near=near, far=far,
+                             use_viewdirs=False, ndc=ndc)
+        return torch.cat([geom, view], -1), [H, W]
     sh = list(rays_d.shape[:-1])
     flat = hip.make_rays(H, W, K, rays_o=rays_o.float(), rays_d=rays_d.float(), near=near, far=far,
                          use_viewdirs=use_viewdirs, ndc=ndc)

@@ -249,11 +249,16 @@ class FusedAdam(torch.optim.Optimizer):
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['step'] += 1
-            step = int(self.state[ps[0]]['step'])
+            # torch.optim.Adam keeps a step count per parameter (a tensor that first receives a gradient later, or a
+            # checkpoint with differing counts): one launch per distinct count, normally exactly one
             b1, b2 = group['betas']
-            hip.adam_step([p.data for p in ps], [p.grad.contiguous() for p in ps],
-                          [self.state[p]['exp_avg'] for p in ps], [self.state[p]['exp_avg_sq'] for p in ps],
-                          step, group['lr'], b1, b2, group['eps'], group['weight_decay'])
+            by_step = {}
+            for p in ps:
+                by_step.setdefault(int(self.state[p]['step']), []).append(p)
+            for step, qs in by_step.items():
+                hip.adam_step([p.data for p in qs], [p.grad.contiguous() for p in qs],
+                              [self.state[p]['exp_avg'] for p in qs], [self.state[p]['exp_avg_sq'] for p in qs],
+                              step, group['lr'], b1, b2, group['eps'], group['weight_decay'])
         return loss
 
 

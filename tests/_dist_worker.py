@@ -58,6 +58,25 @@ def main():
     want = torch.cat([p.grad.reshape(-1) for m in nets for p in m.parameters()])
     res["dp_ok"] = bool(n == got.numel() and torch.allclose(got, want, atol=1e-6))
     res["dp_shard"] = int(xs.shape[0])
+    # ragged shards (15 rays: 8 + 7) and an empty shard (1 ray on 2 ranks): each rank weights its mean-loss gradient
+    # by n_local / n_global before the sum; a rank without rays contributes zeros of the same length
+    res["dp_ragged"] = {}
+    for total in (15, 1):
+        x = torch.randn(total, 5, generator=torch.Generator().manual_seed(21))
+        y = torch.randn(total, 2, generator=torch.Generator().manual_seed(22))
+        for m in nets:
+            m.zero_grad(set_to_none=True)
+        xs, ys = ndist.shard_batch(x, y)
+        if xs.shape[0]:
+            ((nets[1](torch.relu(nets[0](xs))) - ys) ** 2).mean().backward()
+        n = ndist.average_gradients(nets, n_local=xs.shape[0], n_global=total)
+        got = torch.cat([p.grad.reshape(-1) for m in nets for p in m.parameters()])
+        for m in nets:
+            m.zero_grad()
+        ((nets[1](torch.relu(nets[0](x))) - y) ** 2).mean().backward()
+        want = torch.cat([p.grad.reshape(-1) for m in nets for p in m.parameters()])
+        res["dp_ragged"][str(total)] = {"ok": bool(n == got.numel() and torch.allclose(got, want, atol=1e-6)),
+                                        "shard": int(xs.shape[0])}
     torch.distributed.barrier()
     with open(out_path + ".%d" % rank, "w") as f:
         json.dump(res, f)

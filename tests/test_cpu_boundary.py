@@ -69,7 +69,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in _header_decls():
         assert hasattr(L, name), "libnerf_hip.so does not export %s" % name
     lib = hip.lib()
-    assert lib.nerf_hip_abi_version() == hip.ABI_VERSION == 2
+    assert lib.nerf_hip_abi_version() == hip.ABI_VERSION
     assert lib.nerf_last_error() is not None
 
 
@@ -224,18 +224,47 @@ def test_training_entry_points_say_what_is_missing():
         net(torch.zeros(2, 90, requires_grad=True))
 
 
-def test_dropin_alias_modules_resolve_to_the_engine():
-    code = ("import sys; sys.path.insert(0, %r)\n"
+def test_dropin_alias_modules_resolve_to_the_engine(tmp_path):
+    """dropin/ first on sys.path is the zero-edit swap.  The reference's `utils` is a namespace directory without an
+    __init__.py holding many more modules (utils.dist, utils.misc, ...): dropin/utils must merge with it, not shadow it."""
+    other = tmp_path / "ref_side" / "utils"
+    other.mkdir(parents=True)
+    (other / "misc.py").write_text("MARK = 'reference utils.misc'\n")
+    (other / "nerf_utils.py").write_text("raise ImportError('the reference copy must lose to dropin/utils/nerf_utils.py')\n")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(1, %r)\n"
             "import run_nerf, run_multi_nerf, run_nerf_helpers\n"
             "from run_nerf_helpers import *\n"
             "from utils.nerf_utils import create_nerf_model, load_nerf_model, render_path\n"
+            "import utils.misc\n"
+            "assert utils.misc.MARK == 'reference utils.misc'\n"
+            "assert create_nerf_model.__module__.startswith('nerf_loc_amd')\n"
             "assert NeRF.__module__.endswith('helpers') and run_multi_nerf.run_network is run_nerf.run_network\n"
             "for n in ('render', 'render_rays', 'batchify', 'batchify_rays', 'raw2outputs', 'create_nerf', 'render_path',\n"
             "          'sample_pdf', 'get_embedder', 'get_rays', 'get_rays_np', 'ndc_rays', 'img2mse', 'mse2psnr', 'to8b'):\n"
             "    assert callable(getattr(run_nerf, n)), n\n"
-            "print('ALIAS OK')\n") % os.path.join(ROOT, "dropin")
+            "print('ALIAS OK')\n") % (os.path.join(ROOT, "dropin"), str(tmp_path / "ref_side"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
     assert "ALIAS OK" in out.stdout, out.stdout + out.stderr
+    assert not os.path.exists(os.path.join(ROOT, "dropin", "utils", "__init__.py"))
+
+
+def test_graft_entry_build_from_a_clean_tree():
+    """build() is the documented way to produce the library: it must succeed from `make clean` and leave a library
+    whose ABI version is the binding's (a literal version in the entry point once went stale)."""
+    import __graft_entry__ as g
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    code = ("import subprocess, sys, os\n"
+            "subprocess.run(['make', '-C', os.path.join(%r, 'nerf-loc_amd', 'csrc'), 'clean'], check=True, stdout=subprocess.DEVNULL)\n"
+            "import __graft_entry__ as g\n"
+            "g.build()\n"
+            "from nerf_loc_amd import hip\n"
+            "assert hip.lib().nerf_hip_abi_version() == hip.ABI_VERSION\n"
+            "print('BUILD OK')\n") % ROOT
+    if os.environ.get("NERF_SKIP_CLEAN_BUILD_TEST"):
+        pytest.skip("NERF_SKIP_CLEAN_BUILD_TEST set")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert "BUILD OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert callable(g.smoke)
 
 
 def test_ray_bank_batching_mode_follows_the_reference_draws():

@@ -74,6 +74,7 @@ def test_world_size_two_gloo(tmp_path):
     for r, x in enumerate(res):
         assert x["rank"] == r and x["world"] == 2 and x["subset_ok"]
         assert x["dp_ok"] and x["dp_shard"] == 4
+        assert x["dp_ragged"]["15"] == {"ok": True, "shard": 8 - r} and x["dp_ragged"]["1"] == {"ok": True, "shard": 1 - r}
         for n, c in x["cases"].items():
             assert c["ok"], (r, n, c)
     # n = 1: rank 1 holds an empty shard and renders only a 1-ray probe for the key list
