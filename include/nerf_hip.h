@@ -40,8 +40,9 @@ extern "C" {
 #define NERF_IN_RAYS 2        /* in0 = rays [R, ray_cols], in1 = z_vals [R, S]: pts = o + d*z made */
                               /* in registers, never written to memory (render_rays)               */
 
-/* Version of this interface (2: the training entry points take a `precision` argument). */
-#define NERF_HIP_ABI_VERSION 2
+/* Version of this interface (2: the training entry points take a `precision` argument; 3: adds
+ * nerf_mlp_backward_static). */
+#define NERF_HIP_ABI_VERSION 3
 int nerf_hip_abi_version(void);
 const char* nerf_last_error(void);
 
@@ -177,6 +178,22 @@ int nerf_mlp_backward(const void* packed_bwd, const void* packed_fwd, int precis
                       int output_ch, const float* d_raw, long long M, const void* tape,
                       void* grad_tape, float* workspace, size_t workspace_bytes,
                       float* const* grads_host, void* stream);
+
+/* nerf_mlp_backward for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * training / serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (which
+ * allocates freely through PyTorch).  Same arguments and results as nerf_mlp_backward, bit for bit, minus the two
+ * scratch buffers: the gradient tape and the partial-sum workspace live in a static device array of the
+ * library (NERF_STATIC_SCRATCH_BYTES = 163 840 000 bytes, one copy on every GPU the library is used on, held
+ * until the process ends).  Limit: M <= NERF_STATIC_MAX_SAMPLES per call; larger M is refused with
+ * NERF_E_INVALID.  Calls neither hipMalloc nor hipFree nor any allocating routine.  All calls on one GPU share
+ * that GPU's array: calls that overlap in time on one GPU (different streams or threads) race; serialise them.
+ * The first call on a device looks the array's address up (hipGetSymbolAddress); make that call before starting
+ * a graph capture.  The device the stream belongs to must be the current device.                          */
+#define NERF_STATIC_MAX_SAMPLES 8192
+#define NERF_STATIC_SCRATCH_BYTES 163840000
+int nerf_mlp_backward_static(const void* packed_bwd, const void* packed_fwd, int precision, int use_viewdirs,
+                             int output_ch, const float* d_raw, long long M, const void* tape,
+                             float* const* grads_host, void* stream);
 
 /* One Adam update of up to 64 parameter tensors in a single launch: torch.optim.Adam as the
  * reference constructs it (run_nerf.py:225, betas (0.9, 0.999), eps 1e-8, no amsgrad), the

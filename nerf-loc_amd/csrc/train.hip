@@ -19,6 +19,7 @@
 // Bounds: forward and input gradients MFMA (1.19 and 1.11 MFLOP/sample); weight gradients MFMA with
 // 2 KB/sample/layer of tape traffic (HBM-balanced at float32).
 #include <math.h>
+#include <mutex>
 #include "mlp_device.h"
 #include "train_bf16.h"
 #include "wgrad.h"
@@ -535,4 +536,57 @@ extern "C" int nerf_mlp_backward(const void* packed_bwd, const void* packed_fwd,
     }
 #undef NERF_TRY
     return NERF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// nerf_mlp_backward without caller-provided scratch: the gradient tape and the partial-sum workspace live in a
+// static device array of this library, one copy per GPU, held until the process ends.
+// ------------------------------------------------------------------------------------------
+// largest gradient tape at the sample limit: float32, with view directions, rows padded to 128 samples
+constexpr size_t STATIC_GTAPE_BYTES =
+    (size_t)((NERF_STATIC_MAX_SAMPLES + 127) / 128 * 128) * gtape_floats(true) * sizeof(float);
+static_assert(STATIC_GTAPE_BYTES % 256 == 0, "the workspace behind the tape stays 256-byte aligned");
+constexpr size_t STATIC_WS_BYTES = (WG_BIAS_OFFSET + (size_t)WG_MAX_PARTS * 256) * sizeof(float);
+constexpr size_t STATIC_SCRATCH_BYTES = STATIC_GTAPE_BYTES + STATIC_WS_BYTES;
+
+static __device__ __align__(256) unsigned char g_static_scratch[STATIC_SCRATCH_BYTES];
+
+// Device address of g_static_scratch on the CURRENT device.  In host code the array's name is only a handle: the
+// memory is reached through what hipGetSymbolAddress returns, looked up once per device and kept.
+static int static_scratch_base(unsigned char** out) {
+    constexpr int MAX_DEV = 64;
+    static unsigned char* base[MAX_DEV] = {nullptr};
+    static std::mutex mu;
+    int dev = -1;
+    NERF_HIP_CHECK(hipGetDevice(&dev));
+    NERF_REQUIRE(dev >= 0 && dev < MAX_DEV, "nerf_mlp_backward_static: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!base[dev]) {
+        void* p = nullptr;
+        NERF_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch)));
+        NERF_REQUIRE(p && ((uintptr_t)p & 255) == 0, "nerf_mlp_backward_static: bad address of the static scratch array");
+        base[dev] = static_cast<unsigned char*>(p);
+    }
+    *out = base[dev];
+    return NERF_OK;
+}
+
+static_assert(STATIC_SCRATCH_BYTES == NERF_STATIC_SCRATCH_BYTES, "the header states the size of the static array");
+
+extern "C" int nerf_mlp_backward_static(const void* packed_bwd, const void* packed_fwd, int precision, int use_viewdirs,
+                                        int output_ch, const float* d_raw, long long M, const void* tape,
+                                        float* const* grads_host, void* stream) {
+    NERF_REQUIRE(known_precision(precision), "nerf_mlp_backward_static: unknown precision %d", precision);
+    NERF_REQUIRE(M >= 1, "nerf_mlp_backward_static: bad sample count %lld", M);
+    NERF_REQUIRE(M <= NERF_STATIC_MAX_SAMPLES,
+                 "nerf_mlp_backward_static: %lld samples exceed the static scratch (at most %d per call); use "
+                 "nerf_mlp_backward with caller-provided buffers", M, NERF_STATIC_MAX_SAMPLES);
+    NERF_REQUIRE(nerf_train_grad_tape_bytes(M, use_viewdirs, precision) <= STATIC_GTAPE_BYTES,
+                 "nerf_mlp_backward_static: internal size mismatch");
+    unsigned char* base = nullptr;
+    if (int rc = static_scratch_base(&base)) return rc;
+    // nothing in the backward reads scratch it has not written in the same call (the caller-provided buffers of
+    // nerf_mlp_backward are uninitialised as well), so the previous call's contents need no clearing
+    return nerf_mlp_backward(packed_bwd, packed_fwd, precision, use_viewdirs, output_ch, d_raw, M, tape, base,
+                             reinterpret_cast<float*>(base + STATIC_GTAPE_BYTES), STATIC_WS_BYTES, grads_host, stream);
 }

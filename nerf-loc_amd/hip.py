@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "lib", "libnerf_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 2      # 2: the training entry points take a precision argument
+ABI_VERSION = 3      # 2: the training entry points take a precision argument; 3: nerf_mlp_backward_static
 IN_FEATURES, IN_POINTS, IN_RAYS = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
 
@@ -61,6 +61,9 @@ _SIGNATURES = {
     "nerf_mlp_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          _c_float_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, _c_float_p,
                                          ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    "nerf_mlp_backward_static": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                _c_float_p, ctypes.c_longlong, ctypes.c_void_p,
+                                                ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "nerf_adam_step": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.POINTER(ctypes.c_longlong), ctypes.c_longlong, ctypes.c_float,
@@ -382,6 +385,26 @@ def mlp_backward(packed_bwd, use_viewdirs, output_ch, d_raw, tape, shapes, preci
                                        prec, vd, int(output_ch), _ptr(d_raw), M, ctypes.c_void_p(tape.data_ptr()),
                                        ctypes.c_void_p(gtape.data_ptr()), _ptr(ws), ws.numel() * 4, arr,
                                        _stream(d_raw)), "nerf_mlp_backward")
+    return grads
+
+
+STATIC_MAX_SAMPLES = 8192
+
+
+def mlp_backward_static(packed_bwd, use_viewdirs, output_ch, d_raw, tape, grads, precision="fp32", packed_fwd=None):
+    """nerf_mlp_backward_static: as mlp_backward, for callers that may not allocate: the gradient tensors `grads`
+    (state_dict order, None for unused slots) are passed in and overwritten, the scratch is the library's static
+    device array.  At most STATIC_MAX_SAMPLES samples per call."""
+    prec = PRECISIONS[precision]
+    d_raw = _f32(d_raw, "d_raw")
+    M = d_raw.numel() // output_ch
+    arr = (ctypes.c_void_p * len(grads))(*[None if g is None else g.data_ptr() for g in grads])
+    with torch.cuda.device(d_raw.device):
+        _check(lib().nerf_mlp_backward_static(ctypes.c_void_p(packed_bwd.data_ptr()),
+                                              ctypes.c_void_p(packed_fwd.data_ptr()) if packed_fwd is not None else None,
+                                              prec, int(bool(use_viewdirs)), int(output_ch), _ptr(d_raw), M,
+                                              ctypes.c_void_p(tape.data_ptr()), arr, _stream(d_raw)),
+               "nerf_mlp_backward_static")
     return grads
 
 
