@@ -23,6 +23,9 @@ Fixtures (all float32 unless noted):
   g7_linspace.npz     torch.linspace tables the sampling code depends on
   g8_train_step.npz   loss and gradients of one training step
   g9_render.npz       render() on a small image, both API flavours
+  g10_checkpoint.npz  one reference training step (NeRF + torch.optim.Adam) and the checkpoint dict of
+                      run_nerf.py:803-811 written and re-read: key names, optimizer-state layout, and the small
+                      tensors after the step (the full checkpoint is 14 MB and is not stored)
 """
 import os
 import sys
@@ -357,7 +360,61 @@ def g9():
     save("g9_render.npz", **out)
 
 
+# ---------------------------------------------------------------- g10
+def g10():
+    """The reference's optimizer step and checkpoint dict (run_nerf.py:198-239, 770-811) on the g8 batch."""
+    import io
+    import json
+    rays = synth.random_rays(128, seed=8)
+    rs = np.random.RandomState(808)
+    target = rs.uniform(0, 1, size=(128, 3)).astype(np.float32)
+    net_c = make_model(synth.make_state_dict(80, "B"))
+    net_f = make_model(synth.make_state_dict(81, "B"))
+    grad_vars = list(net_c.parameters()) + list(net_f.parameters())
+    optimizer = torch.optim.Adam(params=grad_vars, lr=5e-4, betas=(0.9, 0.999))          # run_nerf.py:213
+    out = {}
+    global_step = 0
+    for it in range(2):
+        r = ref.render_rays(t(rays), net_c, query_fn(), N_samples=64, N_importance=128, network_fine=net_f,
+                            white_bkgd=True, retraw=True, perturb=0.0, raw_noise_std=0.0)
+        optimizer.zero_grad()
+        loss = refh.img2mse(r["rgb_map"], t(target)) + refh.img2mse(r["rgb0"], t(target))
+        loss.backward()
+        optimizer.step()
+        global_step += 1
+        new_lrate = 5e-4 * (0.1 ** (global_step / (250 * 1000)))                       # run_nerf.py:791-795
+        for g in optimizer.param_groups:
+            g["lr"] = new_lrate
+        out["loss_%d" % it] = n(loss)
+    buf = io.BytesIO()
+    torch.save({"global_step": global_step, "network_fn_state_dict": net_c.state_dict(),
+                "network_fine_state_dict": net_f.state_dict(),
+                "optimizer_state_dict": optimizer.state_dict()}, buf)               # run_nerf.py:805-810
+    out["ckpt_bytes"] = np.array(buf.tell())
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=True)
+    osd = ck["optimizer_state_dict"]
+    layout = {"ckpt_keys": list(ck), "opt_keys": list(osd), "n_state": len(osd["state"]),
+              "state_keys": sorted(osd["state"][0]), "step_dtype": str(osd["state"][0]["step"].dtype),
+              "step_shape": list(osd["state"][0]["step"].shape), "step": float(osd["state"][0]["step"]),
+              "group": {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in osd["param_groups"][0].items()},
+              "n_groups": len(osd["param_groups"]), "fn_keys": list(ck["network_fn_state_dict"])}
+    out["layout_json"] = np.array(json.dumps(layout))
+    names = [k for k, _ in net_c.named_parameters()]
+    for pre, net, off in (("c", net_c, 0), ("f", net_f, len(names))):
+        for i, (k, p) in enumerate(net.named_parameters()):
+            if k.endswith("bias") or k.startswith(("alpha_linear", "rgb_linear")):
+                st = osd["state"][off + i]
+                out["%s_param_%s" % (pre, k)] = n(p)
+                out["%s_m_%s" % (pre, k)] = n(st["exp_avg"])
+                out["%s_v_%s" % (pre, k)] = n(st["exp_avg_sq"])
+        out["%s_param_pts0w" % pre] = n(net.pts_linears[0].weight)
+        out["%s_param_pts5w_sub" % pre] = n(net.pts_linears[5].weight[::8, ::11])
+    out["rays"], out["target"] = rays, target
+    save("g10_checkpoint.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for g in which:
         globals()[g]()

@@ -1,0 +1,155 @@
+"""BASELINE configs 2-4 at their full sizes, through properties that hold at any size (the oracle needs minutes
+per 10^5 rays, so it checks samples only): independence of how rays are split over launches or ranks, value ranges,
+sortedness / permutation of the merged depths, NaN pattern of the disparity, linearity of the loss and its gradients
+over the halves of a batch."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from nerf_loc_amd import synth
+from oracle import nerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nerf_loc_amd import hip
+    hip.lib()
+    return torch.device("cuda:0")
+
+
+def _net(sd, dev, precision="fp32", grad=False):
+    from nerf_loc_amd.helpers import NeRF
+    net = NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(dev).requires_grad_(grad)
+    net.precision = precision
+    return net
+
+
+def _query():
+    from nerf_loc_amd import helpers, render
+    return render.NetworkQuery(helpers.get_embedder(10, 0)[0], helpers.get_embedder(4, 0)[0], 1024 * 64)
+
+
+def test_four_million_rays_sharded_like_eight_gpus(dev):
+    """configs[2]: the 4 194 304-ray batch, coarse + fine.  Every rank of an 8-GPU job renders shard_bounds' slice
+    with this same code; the gathered result must equal the unsharded one bit for bit."""
+    from nerf_loc_amd import dist as ndist, hip, render
+    n = 4194304
+    rays = torch.from_numpy(synth.random_rays(n, seed=0)).to(dev)
+    sc, sf = synth.make_state_dict(0, "B"), synth.make_state_dict(1, "B")
+    kw = dict(network_fn=_net(sc, dev, "bf16"), network_query_fn=_query(), N_samples=64, N_importance=128,
+              network_fine=_net(sf, dev, "bf16"), white_bkgd=True)
+    keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
+    whole = ndist.pack_record(render.batchify_rays(rays, 1 << 20, **kw), keys)
+    assert whole.shape == (n, 11)
+    parts = []
+    for r in range(8):
+        lo, hi, per = ndist.shard_bounds(n, r, 8)
+        assert hi - lo == per == n // 8
+        parts.append(ndist.pack_record(render.batchify_rays(rays[lo:hi], 1 << 19, **kw), keys))
+    gathered = torch.cat(parts, 0)
+    same = (gathered == whole) | (torch.isnan(gathered) & torch.isnan(whole))
+    assert bool(same.all())
+    got = ndist.unpack_record(whole, keys)
+    assert float(got["acc_map"].min()) >= 0 and float(got["acc_map"].max()) <= 1 + 1e-5
+    assert float(got["rgb_map"].min()) >= -1e-5 and float(got["rgb_map"].max()) <= 1 + 2e-5
+    assert torch.isfinite(got["rgb_map"]).all() and torch.isfinite(got["z_std"]).all() and float(got["z_std"].min()) >= 0
+    del whole, parts, gathered
+    # hierarchical sampling on the full batch (float32 network for the weights it consumes)
+    z = hip.z_vals(rays, 64)
+    nc = _net(sc, dev, "fp32")
+    raw = hip.mlp_forward(nc.packed_weights(0), 0, True, 4, hip.IN_RAYS, rays, z, n, 64, 11).reshape(n, 64, 4)
+    _, _, acc0, w0, _ = hip.raw2outputs(raw, z, rays[:, 3:6], 11, None, True, want_rgb=False, want_depth=False)
+    del raw
+    assert float((w0.sum(-1) - acc0).abs().max()) < 2e-6 and float(w0.min()) >= 0
+    zs, inds, zsorted, std = hip.sample_pdf(z, w0[:, 1:-1], hip.linspace01(128, dev), bins_are_z=True, z_vals=z,
+                                            want_inds=True, want_sorted=True, want_std=True)
+    assert bool((zsorted[:, 1:] >= zsorted[:, :-1]).all())
+    assert int(inds.min()) >= 1 and int(inds.max()) <= 63
+    assert bool((zs >= z[:, :1]).all()) and bool((zs <= z[:, -1:]).all())
+    for lo in range(0, n, 1 << 20):          # sort(cat) in slices: torch.sort's own workspace is several GB per slice
+        sl = slice(lo, lo + (1 << 20))
+        assert torch.equal(torch.sort(torch.cat([z[sl], zs[sl]], -1), -1)[0], zsorted[sl])
+    # a sample of rays against the oracle: indices and samples bit for bit on the GPU's own weights
+    pick = np.random.RandomState(1).choice(n, 64, replace=False)
+    zp, wp = z[pick].cpu().numpy(), w0[pick].cpu().numpy()
+    mids = (F32(0.5) * (zp[:, 1:] + zp[:, :-1])).astype(F32)
+    ref, ref_i = orc.sample_pdf(mids, wp[:, 1:-1], orc.linspace01(128), return_inds=True)
+    assert np.array_equal(inds[pick].cpu().numpy(), ref_i) and np.array_equal(zs[pick].cpu().numpy(), ref)
+
+
+def test_object_renders_full_size(dev):
+    """configs[3], one object at full size: 2 focal lengths x 8 poses x 240 x 180 rays, 64 samples, coarse network,
+    raw volume kept (model_3detr.py:619-724 through render_path)."""
+    from nerf_loc_amd import nerf_utils
+    args = types.SimpleNamespace(nerf_render_rgb=True, nerf_render_depth=True)
+    _, kw, _ = nerf_utils.create_nerf_model(args, ckpt_path=None, device=dev, near=0.1, far=9.0)
+    # plain random weights with the density bias lowered so that about half of the rays meet no positive density at all
+    # (largest raw density along a ray: 0.032 ... 0.067, median 0.043, measured with the oracle on pose 2)
+    sd = synth.make_state_dict(100, "A")
+    sd["alpha_linear.bias"] = (sd["alpha_linear.bias"] - F32(0.043)).astype(F32)
+    kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    kw["network_fn"].requires_grad_(False)
+    H, W, K, _, _, _ = synth.objectron_camera()
+    poses = [torch.from_numpy(synth.pose_spherical(45.0 * i, -30.0, 4.0)[:3, :4].astype(F32)).to(dev) for i in range(8)]
+    for f in (float(K[0][0]), float(K[0][0]) / 1.2):
+        Kx = np.array([[f, 0, 0.5 * W], [0, f, 0.5 * H], [0, 0, 1]])
+        rgbs, disps, raws, depths = nerf_utils.render_path_device(poses, [H, W, f], Kx, kw)
+        assert tuple(rgbs.shape) == (8, 240, 180, 3) and tuple(raws.shape) == (8, 240, 180, 64, 4)
+        assert tuple(disps.shape) == (8, 240, 180) == tuple(depths.shape)
+        # pose by pose, through the numpy-returning reference interface: identical numbers
+        n_rgbs, n_disps, n_raws, n_depths = nerf_utils.render_path(torch.stack(poses[2:4]), [H, W, f], Kx, 1024 * 32, kw)
+        assert isinstance(n_raws, np.ndarray) and n_raws.shape == (2, 240, 180, 64, 4)
+        assert np.array_equal(n_rgbs, rgbs[2:4].cpu().numpy()) and np.array_equal(n_raws, raws[2:4].cpu().numpy())
+        assert np.array_equal(n_depths, depths[2:4].cpu().numpy())
+        assert np.array_equal(np.isnan(n_disps), np.isnan(disps[2:4].cpu().numpy()))
+        # disparity is NaN exactly where nothing was hit (acc == 0: depth / acc = 0 / 0), depth is then 0
+        _, _, acc, depth, _ = nerf_utils.render(H, W, Kx, chunk=1 << 20, c2w=poses[2], **kw)
+        nan = torch.isnan(disps[2])
+        assert torch.equal(nan, acc == 0) and torch.equal(depth, depths[2])
+        assert bool((depths[2][nan] == 0).all()) and torch.isfinite(depths).all() and torch.isfinite(rgbs).all()
+        print("focal %.1f: %d of %d rays of pose 2 hit nothing (NaN disparity)" % (f, int(nan.sum()), nan.numel()))
+        assert 0 < int(nan.sum()) < nan.numel()
+        assert float(rgbs.min()) >= 0 and float(rgbs.max()) <= 1 + 1e-5
+        assert float(depths.max()) <= 9.0 * (1 + 1e-5)
+
+
+def test_training_step_4096_rays_is_linear_in_its_halves(dev):
+    """configs[4]: a 4096-ray iteration, 64 + 128 samples, float32.  The loss is a mean over rays, so loss and every
+    gradient of the whole batch are the averages of those of its two halves: the property data-parallel training
+    rests on (each rank backpropagates its shard, one all-reduce sums the weighted gradients)."""
+    from nerf_loc_amd import helpers, render
+    rays = torch.from_numpy(synth.random_rays(4096, seed=0)).to(dev)
+    tgt = torch.rand(4096, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    nets = [_net(synth.make_state_dict(s, "B"), dev, grad=True) for s in (0, 1)]
+    kw = dict(network_fn=nets[0], network_query_fn=_query(), N_samples=64, N_importance=128, network_fine=nets[1],
+              white_bkgd=True, perturb=0.0, raw_noise_std=0.0)
+
+    def run(sl):
+        for n in nets:
+            n.zero_grad(set_to_none=True)
+        ret = render.batchify_rays(rays[sl], 1 << 20, **kw)
+        loss = helpers.img2mse(ret["rgb_map"], tgt[sl]) + helpers.img2mse(ret["rgb0"], tgt[sl])
+        loss.backward()
+        grads = [p.grad.clone() for n in nets for p in n.parameters() if p.grad is not None]
+        return float(loss), grads
+
+    l_all, g_all = run(slice(0, 4096))
+    l_a, g_a = run(slice(0, 2048))
+    l_b, g_b = run(slice(2048, 4096))
+    assert len(g_all) == 48 and all(torch.isfinite(g).all() for g in g_all)
+    assert abs(l_all - 0.5 * (l_a + l_b)) < 1e-6 * max(1.0, abs(l_all))
+    worst = 0.0
+    for g, a, b in zip(g_all, g_a, g_b):
+        worst = max(worst, float((g - 0.5 * (a + b)).norm() / (g.norm() + 1e-30)))
+    print("4096-ray step: loss %.6f = mean of halves %.6f; worst relative gradient difference %.3e"
+          % (l_all, 0.5 * (l_a + l_b), worst))
+    assert worst < 1e-4

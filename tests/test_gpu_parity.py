@@ -82,6 +82,43 @@ def test_make_rays_and_ndc(dev, golden):
     assert maxabs(N(nd), g["ndc_d"]) < 1e-5 * max(1, np.abs(g["ndc_d"]).max())
 
 
+def test_static_camera_rays(dev):
+    """c2w_staticcam (run_nerf.py:102-107): consulted only with use_viewdirs; geometry then comes from the static
+    camera, view directions from c2w (or from the given ray batch, which must then have H*W rays)."""
+    from nerf_loc_amd import render
+    H, W, K, c2w, near, far = synth.lego_camera(16, theta=40.0)
+    static = synth.pose_spherical(-75.0, -20.0, 3.5)[:3, :4].astype(F32)
+    so, sd = orc.get_rays(H, W, K, static)
+    vo, vd = orc.get_rays(H, W, K, c2w.astype(F32))
+    want = orc.pack_rays(so, sd, near, far, True, viewdirs_from=vd)
+    flat, sh = render._build_rays(H, W, K, None, T(c2w.astype(F32), dev), False, near, far, True, T(static, dev))
+    assert sh == [H, W] and maxabs(N(flat)[:, :8], want[:, :8]) < 1e-6 and maxabs(N(flat)[:, 8:], want[:, 8:]) < 2e-7
+    # without view directions the static camera is ignored
+    flat0, _ = render._build_rays(H, W, K, None, T(c2w.astype(F32), dev), False, near, far, False, T(static, dev))
+    assert maxabs(N(flat0), orc.pack_rays(vo, vd, near, far, False)) < 1e-6
+    # a ray batch as the source of the view directions
+    rb = (T(vo.reshape(-1, 3), dev), T(vd.reshape(-1, 3), dev))
+    flat2, sh2 = render._build_rays(H, W, K, rb, None, False, near, far, True, T(static, dev))
+    assert sh2 == [H, W] and torch.equal(flat2, flat)
+    with pytest.raises(ValueError):
+        render._build_rays(H, W, K, (rb[0][:7], rb[1][:7]), None, False, near, far, True, T(static, dev))
+    flat3, sh3 = render._build_rays(H, W, K, (rb[0][:7], rb[1][:7]), None, False, near, far, False, T(static, dev))
+    assert sh3 == [7] and maxabs(N(flat3), orc.pack_rays(vo, vd, near, far, False)[:7]) < 1e-6
+
+
+def test_ndc_rays_any_near_plane(dev):
+    """ndc_rays takes the near plane as an argument (run_nerf_helpers.py:175-192); render() passes 1.0, callers may not."""
+    from nerf_loc_amd import helpers
+    rs = np.random.RandomState(4)
+    o = (rs.uniform(-1, 1, size=(64, 3)) + np.array([0, 0, 0.5])).astype(F32)
+    d = rs.normal(size=(64, 3)).astype(F32)
+    d[:, 2] = -np.abs(d[:, 2]) - 0.2
+    for near in (1.0, 0.5, 2.0):
+        no, nd = helpers.ndc_rays(378, 504, 407.5, near, T(o, dev), T(d, dev))
+        ro, rd = orc.ndc_rays(378, 504, 407.5, near, o, d)
+        assert maxabs(N(no), ro) < 1e-5 * max(1, np.abs(ro).max()) and maxabs(N(nd), rd) < 1e-5 * max(1, np.abs(rd).max())
+
+
 def test_z_vals(dev):
     from nerf_loc_amd import hip
     rays = synth.random_rays(300, seed=3, near=0.1, far=9.0)
@@ -237,7 +274,8 @@ def test_mlp_bf16_close_to_fp32(dev, golden):
         err = np.abs(out - ref)
         scale = np.abs(ref).max()
         print("bf16 raw regime %s: max %.3e mean %.3e (scale %.2f)" % (regime, err.max(), err.mean(), scale))
-        assert err.max() < 3e-2 * max(1.0, scale) and err.mean() < 4e-3 * max(1.0, scale)
+        # measured 4.9e-4 (scale 0.2) and 1.6e-2 (scale 2.4, i.e. 6.6e-3 of it): bounds are twice that
+        assert err.max() < 1.4e-2 * max(1.0, scale) and err.mean() < 2.5e-3 * max(1.0, scale)
 
 
 def test_mlp_ragged_sizes(dev):
@@ -280,21 +318,29 @@ def test_render_rays_fp32_stagewise(dev, golden, regime):
                            white_bkgd=True)
     r = {k: N(v) for k, v in r.items()}
     tag = "cf_" + regime
+    # Conditioning mask from the reference's own float64 rerun (never from the output under test): the last interval
+    # is 1e10 long, so a ray whose last density is within float32 rounding of the ReLU kink can flip its last alpha.
     raw_last = g["cf64_%s_rawlast" % regime]
-    mask = np.abs(raw_last) > 1e-4          # rays whose last density is within rounding of the ReLU kink flip the 1e10-long last interval
-    print("regime %s: %d of %d rays masked as ill-conditioned" % (regime, (~mask).sum(), mask.size))
-    for k in ("rgb0", "acc0"):
+    mask = np.abs(raw_last) > 1e-4
+    print("regime %s: %d of %d rays masked as ill-conditioned (|last sigma| of the float64 run <= 1e-4)"
+          % (regime, (~mask).sum(), mask.size))
+    assert (~mask).sum() == 0            # the fixture's rays are all well conditioned: nothing is excluded below
+    for k in ("rgb0", "acc0", "disp0"):
         e = maxabs(r[k], g["%s_%s" % (tag, k)])
         print("  coarse %s max abs err %.3e" % (k, e))
         assert e < 1e-4, k
-    # free-running fine pass against the golden run (the teacher-forced test below holds the 1e-4 bar)
-    for k in ("rgb_map", "acc_map"):
+    # free-running fine pass (importance samples drawn from the GPU's own coarse weights) against the reference run:
+    # the north star's 1e-4 absolute on every ray
+    for k in ("rgb_map", "acc_map", "disp_map"):
         e_all = maxabs(r[k], g["%s_%s" % (tag, k)])
-        e_mask = maxabs(r[k][mask], g["%s_%s" % (tag, k)][mask])
-        print("  fine %s max abs err: all rays %.3e, conditioned rays %.3e" % (k, e_all, e_mask))
-        assert e_mask < (1e-4 if regime == "A" else 5e-3), k    # regime B: free-running samples, see below
-    # spread of the free-running importance samples; equal unless a sample sits where the pdf is on its 1e-5 floor
-    assert maxabs(r["z_std"], g[tag + "_z_std"]) < 5e-4
+        print("  fine %s max abs err on all %d rays %.3e" % (k, mask.size, e_all))
+        assert e_all < 1e-4, k
+    # z_std is not one of the contract maps (rgb, depth, acc); the reference's own float32 result is 1e-4 from its
+    # float64 rerun.  Measured 9.0e-5 (A) and 2.6e-5 (B): the bound is twice the larger.
+    e = maxabs(r["z_std"], g[tag + "_z_std"])
+    e64 = maxabs(g[tag + "_z_std"], g["cf64_%s_z_std" % regime].astype(np.float32))
+    print("  z_std max abs err %.3e (the reference's float32 vs its float64 run: %.3e)" % (e, e64))
+    assert e < 2e-4
 
 
 @pytest.mark.parametrize("regime", ["A", "B"])
@@ -317,7 +363,9 @@ def test_render_rays_fp32_teacher_forced(dev, golden, regime):
     print("regime %s coarse raw err %.3e (scale %.1f)" % (regime, maxabs(N(raw), o["raw"]), scale))
     assert maxabs(N(raw), o["raw"]) < 2e-5 * scale
     assert maxabs(N(rgb0), o["rgb_map"]) < 1e-4 and maxabs(N(acc0), o["acc_map"]) < 1e-4
-    assert maxabs(N(depth0), o["depth_map"]) < 1e-4 * 6
+    e = maxabs(N(depth0), o["depth_map"])
+    print("  coarse depth max abs err %.3e (depths 2..6)" % e)
+    assert e < 1e-4
     # importance sampling on the GPU's weights: bit-exact against the oracle on the same weights
     u = orc.linspace01(128)
     w_np, z_np = N(w0), N(z)
@@ -344,7 +392,7 @@ def test_render_rays_fp32_teacher_forced(dev, golden, regime):
         e = maxabs(N(a)[sens], b[sens])
         print("  fine %s max abs err %.3e (%d rays excluded: last sigma within 1e-3 of the relu kink)"
               % (name, e, (~sens).sum()))
-        assert e < 1e-4 * (6 if name == "depth" else 1), name
+        assert e < 1e-4, name
 
 
 def _embedders():
@@ -407,7 +455,7 @@ def test_render_image_both_flavours(dev, golden):
     assert maxabs(N(extras["rgb0"]), g["lego_rgb0"]) < 1e-4 and maxabs(N(extras["acc0"]), g["lego_acc0"]) < 1e-4
     e = maxabs(N(rgb), g["lego_rgb"])
     print("render() 20x20 coarse+fine free-running rgb err %.3e" % e)
-    assert e < 5e-3     # free-running importance samples: see test_render_rays_fp32_teacher_forced for the 1e-4 bar
+    assert e < 1e-4 and maxabs(N(acc), g["lego_acc"]) < 1e-4      # free-running importance samples, every pixel
     # rays= entry: [2, N, 3]
     rays = g["batch_rays"]
     ro, rd = T(rays[:, :3].copy(), dev), T(rays[:, 3:6].copy(), dev)
@@ -423,7 +471,9 @@ def test_render_image_both_flavours(dev, golden):
     rgb, disp, acc, depth, extras = nerf_utils.render(H, W, g["loc_K"], chunk=1024 * 32, c2w=T(g["loc_c2w"], dev),
                                                       **kw_test)
     assert maxabs(N(rgb), g["loc_rgb"]) < 1e-4 and maxabs(N(acc), g["loc_acc"]) < 1e-4
-    assert maxabs(N(depth), g["loc_depth"]) < 1e-4 * 9
+    e = maxabs(N(depth), g["loc_depth"])
+    print("NeRF-Loc render() depth max abs err %.3e (depths 0.1..9)" % e)
+    assert e < 1e-4
     assert maxabs(N(extras["raw"]), g["loc_raw"]) < 2e-5 * max(1.0, np.abs(g["loc_raw"]).max())
     poses = torch.stack([T(g["loc_c2w"], dev)] * 2)
     rgbs, _, raws, depths = nerf_utils.render_path(poses, [H, W, float(g["loc_K"][0, 0])], g["loc_K"], 1024 * 32,
@@ -442,41 +492,79 @@ def _psnr(a, b):
     return -10.0 * np.log10(float(((a.astype(np.float64) - b) ** 2).mean()))
 
 
-@pytest.mark.parametrize("seed,kind,tol", [(62, "opaque", 1e-2), (66, "mixed", 1e-2), (64, "fog", 5e-2)])
-def test_render_bf16_vs_fp32(dev, seed, kind, tol):
-    """bf16-MFMA mode against the float32 mode on the same rays and weights: rgb / acc within 1e-2 absolute, and
-    the PSNR against a common 30 dB target image moves by less than 0.1 dB.  The opaque scene (every ray ends in
-    dense matter) is held to the bar on all rays; the mixed scenes on the rays whose float32 result is not within
-    rounding of the 1e10-wide last interval switching on (sigma of the last sample near zero).  The "fog" scene has
-    rays that cross 4 units of barely positive density (acc 0.03-0.1, a state trained networks do not sit in): there
-    the bf16 rounding of 192 near-zero densities adds up coherently, the absolute bar is 5e-2 and the PSNR bar holds."""
+# |last raw density| below this is within the bf16 rounding of the network output: three times the measured worst
+# error of the raw output (4.9e-4 for plain random weights, raw values of magnitude 0.2; 1.6e-2 for the "trained-like"
+# weights, magnitude 2.4; see test_mlp_bf16_close_to_fp32)
+BF16_KINK = {"A": 1.5e-3, "B": 0.05}
+
+
+@pytest.mark.parametrize("regime", ["A", "B"])
+def test_render_bf16_vs_reference_golden(dev, golden, regime):
+    """bf16-MFMA mode against the REFERENCE's float32 outputs (g5: render_rays of nerf-pytorch on these rays and
+    weights): rgb / acc within 1e-2 absolute, PSNR against a common 30 dB target within 0.1 dB.  Rays are excluded
+    only by the reference's own float64 rerun (last density within bf16 rounding of the ReLU kink, where the 1e10-long
+    last interval switches on or off); the count is asserted."""
     from nerf_loc_amd import render
-    rays = synth.random_rays(4096, seed=21)
+    g = golden("g5_render_rays")
+    rays = g["rays"]
+    nc = load_net(synth.make_state_dict(50, regime), dev, precision="bf16")
+    nf = load_net(synth.make_state_dict(51, regime), dev, precision="bf16")
+    r = render.render_rays(T(rays, dev), nc, _query(dev), 64, N_importance=128, network_fine=nf, white_bkgd=True)
+    r = {k: N(v) for k, v in r.items()}
+    cond = np.abs(g["cf64_%s_rawlast" % regime]) > BF16_KINK[regime]
+    n_masked = int((~cond).sum())
+    ref_rgb, ref_acc = g["cf_%s_rgb_map" % regime], g["cf_%s_acc_map" % regime]
+    err = np.abs(r["rgb_map"] - ref_rgb).max(-1)
+    e_acc = np.abs(r["acc_map"] - ref_acc)
+    np.random.seed(5)
+    target = ref_rgb.astype(np.float64) + np.random.randn(*ref_rgb.shape) * 10 ** (-30 / 20)
+    dpsnr = abs(_psnr(r["rgb_map"][cond], target[cond]) - _psnr(ref_rgb[cond], target[cond]))
+    print("regime %s bf16 vs reference: rgb max %.3e, acc max %.3e on %d conditioned rays (%d masked by the float64 run; "
+          "all rays rgb %.3e), coarse rgb0 max %.3e, PSNR shift at 30 dB %.4f dB"
+          % (regime, err[cond].max(), e_acc[cond].max(), cond.sum(), n_masked, err.max(),
+             np.abs(r["rgb0"] - g["cf_%s_rgb0" % regime]).max(), dpsnr))
+    assert n_masked == {"A": 5, "B": 0}[regime]
+    assert err[cond].max() < 1e-2 and e_acc[cond].max() < 1e-2
+    assert dpsnr < 0.1
+
+
+_FOG = pytest.mark.xfail(strict=True, reason="known violation of the 1e-2 bar: rays through 4 units of barely positive "
+                         "density (acc 0.03-0.1) sum the bf16 rounding of 192 near-zero densities coherently; measured "
+                         "rgb max 3.6e-2 (PSNR shift 0.03 dB, inside its bar)")
+
+
+@pytest.mark.parametrize("seed,kind", [(62, "opaque"), (66, "mixed"), pytest.param(64, "fog", marks=_FOG)])
+def test_render_bf16_vs_oracle_scenes(dev, seed, kind):
+    """bf16-MFMA mode on three synthetic scenes against the numpy oracle (the restatement pinned to the reference
+    by the golden fixtures) in float32; the conditioning mask comes from the oracle's float64 run of the same rays,
+    never from the output under test.  Bars: 1e-2 absolute on rgb and acc, 0.1 dB PSNR.  The opaque scene (every ray
+    ends in dense matter) must hold them on every ray."""
+    from nerf_loc_amd import render
+    rays = synth.random_rays(2048, seed=21)
     sc, sf = synth.make_state_dict(seed, "B"), synth.make_state_dict(seed + 1, "B")
-    out = {}
-    for prec in ("fp32", "bf16"):
-        nc, nf = load_net(sc, dev, precision=prec), load_net(sf, dev, precision=prec)
-        r = render.render_rays(T(rays, dev), nc, _query(dev), 64, retraw=True, N_importance=128, network_fine=nf,
-                               white_bkgd=True)
-        out[prec] = {k: N(v) for k, v in r.items()}
-    f, b = out["fp32"], out["bf16"]
-    # the last interval is 1e10 long: its alpha is a step function of the last sample's raw density, so a ray is
-    # comparable only if that density is further from zero than the bf16 rounding of the network output
-    cond = (np.abs(f["raw"][:, -1, 3]) > 0.05) & (np.sign(f["raw"][:, -1, 3]) == np.sign(b["raw"][:, -1, 3]))
+    nc, nf = load_net(sc, dev, precision="bf16"), load_net(sf, dev, precision="bf16")
+    b = render.render_rays(T(rays, dev), nc, _query(dev), 64, retraw=True, N_importance=128, network_fine=nf,
+                           white_bkgd=True)
+    b = {k: N(v) for k, v in b.items()}
+    f = orc.render_rays(rays, sc, 64, 128, sd_fine=sf, white_bkgd=True, retraw=True)
+    f64 = orc.render_rays(rays.astype(np.float64), sc, 64, 128, sd_fine=sf, white_bkgd=True, retraw=True)
+    cond = np.abs(f64["raw"][:, -1, 3]) > BF16_KINK["B"]
     assert kind != "opaque" or cond.all()
     err = np.abs(b["rgb_map"] - f["rgb_map"])
     np.random.seed(5)
     target = f["rgb_map"].astype(np.float64) + np.random.randn(*f["rgb_map"].shape) * 10 ** (-30 / 20)
     dpsnr = abs(_psnr(b["rgb_map"][cond], target[cond]) - _psnr(f["rgb_map"][cond], target[cond]))
-    print("seed %d (%s) bf16 vs fp32: rgb max %.3e on %d conditioned rays (all rays %.3e), mean %.3e, "
-          "PSNR shift at 30 dB %.4f dB" % (seed, kind, err[cond].max(), cond.sum(), err.max(), err.mean(), dpsnr))
+    print("seed %d (%s) bf16 vs oracle: rgb max %.3e on %d conditioned rays (%d masked by the float64 run; all rays "
+          "%.3e), mean %.3e, acc max %.3e, PSNR shift at 30 dB %.4f dB"
+          % (seed, kind, err[cond].max(), cond.sum(), (~cond).sum(), err.max(), err.mean(),
+             np.abs(b["acc_map"] - f["acc_map"])[cond].max(), dpsnr))
     worst = np.argsort(err.max(-1) * cond)[-3:]
-    print("  worst conditioned rays: err %s, last raw density fp32 %s bf16 %s, acc fp32 %s"
-          % (err.max(-1)[worst], f["raw"][worst, -1, 3], b["raw"][worst, -1, 3], f["acc_map"][worst]))
+    print("  worst conditioned rays: err %s, last raw density float64 %s bf16 %s, acc %s"
+          % (err.max(-1)[worst], f64["raw"][worst, -1, 3], b["raw"][worst, -1, 3], f["acc_map"][worst]))
     assert cond.sum() > 0.5 * cond.size
-    assert err[cond].max() < tol
-    assert maxabs(b["acc_map"][cond], f["acc_map"][cond]) < tol
     assert dpsnr < 0.1
+    assert err[cond].max() < 1e-2
+    assert maxabs(b["acc_map"][cond], f["acc_map"][cond]) < 1e-2
 
 
 # ------------------------------------------------------------------ edge cases
