@@ -81,6 +81,9 @@ struct Pipe {
         // fragment queue into lgkmcnt(0).  The loads are waited for by hand (advance()).
         const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr + issue_slot * STAGE_BYTES + wave_off);
         unsigned keep;
+#ifdef NERF_EXP_NODMA     // timing experiment only (results are garbage): what the LDS-DMA issue costs the wave
+        (void)keep; (void)m0v; (void)gs;
+#else
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
             "s_mov_b32 m0, %2\n\t"
@@ -93,6 +96,7 @@ struct Pipe {
             : "=&s"(keep)
             : "v"(src_off), "s"(m0v), "s"(gs)
             : "memory");
+#endif
         issue_src = (issue_src + 1 == n_stages) ? 0 : issue_src + 1;
         issue_slot = (issue_slot + 1) & (NSTAGE - 1);
     }
@@ -100,7 +104,9 @@ struct Pipe {
     __device__ __forceinline__ void advance() {
         issue();
         asm volatile("s_waitcnt vmcnt(" NERF_VMCNT_KEEP ")" ::: "memory");
+#ifndef NERF_EXP_NOBARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void next_stage() {
