@@ -18,21 +18,11 @@
 // Bound: MFMA.  1 186 816 algorithmic FLOP per sample (1 212 416 issued with padding).
 #include <type_traits>
 #include "mlp_bf16.h"
+#include "mlp16.h"
 #include "train_bf16.h"
 
 namespace nerf {
 
-
-#ifdef NERF_EXP_STAMP
-// diagnostic build only: per-block cycle sums {input+encoding, layers 0-4, layer 5-7, heads, store, passes}
-__device__ unsigned long long g_stamps[256 * 8];
-#define NERF_STAMP(var)                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");              \
-    __builtin_amdgcn_sched_barrier(0);
-#else
-#define NERF_STAMP(var)
-#endif
 
 // TAPE: the training forward.  Every layer input a weight gradient needs is also stored, in the operand layout it
 // has in the registers (train_bf16.h).
@@ -478,6 +468,81 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     }
 }
 
+// The same network as the 16x16x32 stream of the bf16 inference kernel (mlp16.h): fragments of 16 output rows x 32
+// k-slots, bias tiles of 16 floats, the output scales computed above folded in the same way.
+__device__ __forceinline__ const float* pack_row16(const PackArgs& a, const LayerDesc& L, int tile, int r, bool bias, int& row) {
+    row = -1;
+    switch (L.kind) {
+        case LK_HIDDEN:
+            row = tile * 16 + r;
+            if (row >= L.out_dim) { row = -1; return nullptr; }
+            return a.t[bias ? L.b_idx : L.w_idx];
+        case LK_FEATURE_ALPHA:
+            if (tile < 16) { row = tile * 16 + r; return a.t[bias ? L.b_idx : L.w_idx]; }
+            if (r == 3) { row = 0; return a.t[bias ? L.b2_idx : L.w2_idx]; }      // the density row
+            return nullptr;
+        default:   // LK_RGB, LK_OUTPUT: rows 0..out_dim-1 of a single tile
+            if (r < L.out_dim) { row = r; return a.t[bias ? L.b_idx : L.w_idx]; }
+            return nullptr;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack16_kernel(PackArgs a, unsigned char* out16, int padded_frags, int n_bias_tiles16,
+                                                     const float* scales) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int F = gid >> 6, lane = gid & 63;
+    const int r = lane & 15, gg = lane >> 4;
+    if (F < padded_frags) {
+        int f = F, li = 0;
+        for (; li < a.net.n_layers; ++li) {
+            const int nf = tiles16(a.net.layer[li]) * ksteps16(a.net.layer[li]);
+            if (f < nf) break;
+            f -= nf;
+        }
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.0f;
+        if (li < a.net.n_layers) {
+            const LayerDesc& L = a.net.layer[li];
+            const int ks = ksteps16(L);
+            const int tile = f / ks, kk = f - tile * ks;
+            int row;
+            const float* W = pack_row16(a, L, tile, r, false, row);
+            const bool head_row = L.kind == LK_FEATURE_ALPHA && tile == 16;
+            const float s_out = (L.scaled_out && !head_row) ? scales[li] : 1.0f;
+            const float s_hid = L.src_layer >= 0 ? scales[L.src_layer] : 1.0f;
+            const int npe = L.has_pe ? 2 : 0, nh = L.hid_feats / 32;
+            for (int j = 0; j < 8; ++j) {
+                int col = -1;
+                const bool hidden = kk >= npe && kk < npe + nh;
+                if (kk < npe) { const int ft = pe16_slot_feature(gg, 8 * kk + j); col = ft < 0 ? -1 : L.pe_col + ft; }
+                else if (hidden) col = L.hid_col + 32 * (kk - npe) + 16 * (j >> 2) + 4 * gg + (j & 3);
+                else { const int ft = view16_slot_feature(gg, j); col = ft < 0 ? -1 : L.view_col + ft; }
+                float w = (W && col >= 0) ? W[(size_t)row * L.in_dim + col] : 0.0f;
+                w *= hidden ? s_out / s_hid : s_out;
+                v[j] = (__bf16)w;
+            }
+        }
+        *reinterpret_cast<bf16x8*>(out16 + (size_t)F * FRAG_BYTES + lane * 16) = v;
+    } else {
+        const int bi = gid - padded_frags * 64;
+        if (bi >= n_bias_tiles16 * 16) return;
+        int t = bi >> 4, li = 0;
+        const int rr = bi & 15;
+        for (; li < a.net.n_layers; ++li) {
+            if (t < tiles16(a.net.layer[li])) break;
+            t -= tiles16(a.net.layer[li]);
+        }
+        const LayerDesc& L = a.net.layer[li];
+        int row;
+        const float* Bp = pack_row16(a, L, t, rr, true, row);
+        float b = Bp ? Bp[row] : 0.0f;
+        const bool head_row = L.kind == LK_FEATURE_ALPHA && t == 16;
+        if (L.scaled_out && !head_row) b *= scales[li];
+        reinterpret_cast<float*>(out16 + (size_t)padded_frags * FRAG_BYTES)[bi] = b;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // MFMA lane-map self test (exact small integers, asymmetric operands)
 // ------------------------------------------------------------------------------------------
@@ -506,6 +571,18 @@ __global__ void selftest_kernel(int* bad) {
         for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * h, col = r;
             const float ref = Aval(row, 0) * Bval(0, col) + Aval(row, 1) * Bval(1, col);
+            if (acc[e] != ref) ++nbad;
+        }
+    }
+    {   // bf16 16x16x32: A[row c][k = 8g + j], B[k = 8g + j][col c]; result rows 4g + e of column c
+        const int c = lane & 15, g = lane >> 4;
+        bf16x8 fa, fb;
+        for (int j = 0; j < 8; ++j) { fa[j] = (__bf16)Aval(c, 8 * g + j); fb[j] = (__bf16)Bval(8 * g + j, c); }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+            float ref = 0.f;
+            for (int k = 0; k < 32; ++k) ref += Aval(4 * g + e, k) * Bval(k, c);
             if (acc[e] != ref) ++nbad;
         }
     }
@@ -572,11 +649,20 @@ static int frag_total(int precision, int use_viewdirs) {
     return use_viewdirs ? FRAGS_F32_VD : FRAGS_F32_NOVD;
 }
 
+// bf16 buffer: [32x32x16 stream | its bias tiles | scales | row-sum scratch] as the training kernels read it, then
+// [16x16x32 stream | its bias tiles] for the inference kernel
+static size_t stream16_offset(int use_viewdirs) {
+    return (size_t)frag_total(NERF_PREC_BF16, use_viewdirs) * FRAG_BYTES +
+           (size_t)(use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD) * BIAS_TILE_BYTES + SCALE_BYTES + ROWSUM_BYTES;
+}
+
 extern "C" size_t nerf_mlp_packed_bytes(int precision, int use_viewdirs) {
     if (precision != NERF_PREC_BF16 && precision != NERF_PREC_F32) return 0;
+    if (precision == NERF_PREC_BF16)
+        return stream16_offset(use_viewdirs) + (size_t)frag_total(NERF_PREC_BF16, use_viewdirs) * FRAG_BYTES +
+               bias16_block_bytes(use_viewdirs != 0);
     return (size_t)frag_total(precision, use_viewdirs) * FRAG_BYTES +
-           (size_t)(use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD) * BIAS_TILE_BYTES + SCALE_BYTES +
-           (precision == NERF_PREC_BF16 ? ROWSUM_BYTES : 0);
+           (size_t)(use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD) * BIAS_TILE_BYTES + SCALE_BYTES;
 }
 
 extern "C" int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs, int output_ch, int precision,
@@ -599,7 +685,17 @@ extern "C" int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs,
         if (use_viewdirs || (i != 16 && i != 17)) NERF_REQUIRE(a.t[i], "nerf_mlp_pack: tensor %d is null", i);
     a.out = static_cast<unsigned char*>(packed_out);
     a.padded_frags = a.total_frags;
-    return launch_pack(a, as_stream(stream));
+    if (int rc = launch_pack(a, as_stream(stream))) return rc;
+    if (a.bf16) {
+        const int nb16 = use_viewdirs ? BIAS_TILES16_VD : BIAS_TILES16_NOVD;
+        const float* scales = reinterpret_cast<const float*>(a.out + (size_t)a.padded_frags * FRAG_BYTES +
+                                                             (size_t)a.net.n_bias_tiles * BIAS_TILE_BYTES);
+        const int threads = a.total_frags * 64 + nb16 * 16;
+        hipLaunchKernelGGL(pack16_kernel, dim3((threads + 255) / 256), dim3(256), 0, as_stream(stream), a,
+                           a.out + stream16_offset(use_viewdirs), a.total_frags, nb16, scales);
+        NERF_LAUNCH_CHECK();
+    }
+    return NERF_OK;
 }
 
 extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int output_ch, int input_mode,
@@ -636,9 +732,11 @@ extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewd
     const int grid = (int)(n_tiles < cu_count() ? n_tiles : cu_count());
     hipStream_t st = as_stream(stream);
     if (precision == NERF_PREC_BF16) {
-        if (use_viewdirs) hipLaunchKernelGGL((mlp_bf16_kernel<true, 4, false>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
-        else if (output_ch == 4) hipLaunchKernelGGL((mlp_bf16_kernel<false, 4, false>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
-        else hipLaunchKernelGGL((mlp_bf16_kernel<false, 5, false>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+        a.packed += stream16_offset(use_viewdirs);
+        a.n_bias_tiles = ((use_viewdirs ? BIAS_TILES16_VD : BIAS_TILES16_NOVD) * 16 + 31) / 32;    // in units of 32 floats
+        if (use_viewdirs) hipLaunchKernelGGL((m16::mlp16_bf16_kernel<true, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+        else if (output_ch == 4) hipLaunchKernelGGL((m16::mlp16_bf16_kernel<false, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((m16::mlp16_bf16_kernel<false, 5>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
     } else {
         if (use_viewdirs) hipLaunchKernelGGL((mlp_f32_kernel<true, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
         else if (output_ch == 4) hipLaunchKernelGGL((mlp_f32_kernel<false, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);

@@ -14,6 +14,17 @@
 
 namespace nerf {
 
+#ifdef NERF_EXP_STAMP
+// diagnostic build only: per-block cycle sums {input+encoding, layers 0-4, layer 5-7, heads, store, passes}
+static __device__ unsigned long long g_stamps[256 * 8];
+#define NERF_STAMP(var)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define NERF_STAMP(var)
+#endif
+
 constexpr int NCT = 2;
 #ifndef NERF_PF
 #define NERF_PF 3

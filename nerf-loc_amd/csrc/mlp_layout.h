@@ -89,6 +89,32 @@ __host__ __device__ constexpr int view_slot_feature(int h, int q) {
     return -1;
 }
 
+// ---- v_mfma_f32_16x16x32_bf16 conventions (the bf16 INFERENCE kernel, mlp16.h; g = lane >> 4, c = lane & 15) ----------
+// A fragment = 16 output rows x 32 k-slots: lane (c, g) holds row c, slots (g, j), j = 0..7.  B operand = 32 k-slots x 16
+// samples: lane (c, g) holds sample c, slots (g, j).  Result: lane (c, g) holds sample c, rows 4 g + reg, reg = 0..3.
+//   hidden k-step s : slot (g, j) <-> input feature 32 s + 16 (j >> 2) + 4 g + (j & 3)
+//                     = accumulator register j & 3 of the 16-row output tile 2 s + (j >> 2) of the previous layer
+//   encoded points  : 2 k-steps; lane group g computes 16 values, "slot q" = 8 (k-step) + j = 4 m + t with
+//                     t = 0 sin(f0), 1 cos(f0), 2 sin(f0 + 1), 3 cos(f0 + 1) (octaves f0, f0 + 1 of one coordinate):
+//                     m < 3: coordinate m, f0 = 2 g;  m = 3: g < 3: coordinate g, f0 = 8;  g = 3: x, y, z, zero padding
+//   encoded view    : 1 k-step; g < 3: coordinate g, slot j = 2 f + (1 if cos), f = 0..3;  g = 3: dx, dy, dz, zeros
+__host__ __device__ constexpr int pe16_slot_feature(int g, int q) {
+    const int m = q >> 2, t = q & 3;
+    if (m == 3 && g == 3) return t < 3 ? t : -1;
+    return 3 + 6 * ((m < 3 ? 2 * g : 8) + (t >> 1)) + 3 * (t & 1) + (m < 3 ? m : g);
+}
+__host__ __device__ constexpr int view16_slot_feature(int g, int j) {
+    if (g == 3) return j < 3 ? j : -1;
+    return 3 + 6 * (j >> 1) + 3 * (j & 1) + g;
+}
+// 16-row output tiles and 32-slot k-steps of a (forward) layer in this layout
+__host__ __device__ constexpr int tiles16(const LayerDesc& L) {
+    return L.kind == LK_HIDDEN ? L.out_dim / 16 : (L.kind == LK_FEATURE_ALPHA ? 17 : 1);
+}
+__host__ __device__ constexpr int ksteps16(const LayerDesc& L) {
+    return (L.has_pe ? 2 : 0) + L.hid_feats / 32 + (L.has_view ? 1 : 0);
+}
+
 inline NetDesc make_net_desc(bool use_viewdirs, int output_ch) {
     NetDesc n{};
     int li = 0, bt = 0;
@@ -183,6 +209,15 @@ constexpr int BIAS_TILE_BYTES = 32 * 4;
 constexpr int SCALE_BYTES = 64;                  // MAX_LAYERS output scales behind the bias block
 constexpr int ROWSUM_BYTES = MAX_LAYERS * 256 * 2 * 4;   // behind the scales: pack-time scratch (per-row |W| sums)
 constexpr float INPUT_BOUND = 16777216.0f;       // |network input| assumed <= 2^24 when the scales are chosen
+
+// The 16x16x32 stream of the inference kernel: 1172 / 968 fragments, zero-padded to the same totals as above
+constexpr int FRAGS16_VD = 16 * 2 + 4 * 16 * 8 + 16 * 10 + 2 * 16 * 8 + 17 * 8 + 8 * 9 + 4;     // 1172
+constexpr int FRAGS16_NOVD = 16 * 2 + 4 * 16 * 8 + 16 * 10 + 2 * 16 * 8 + 8;                     // 968
+constexpr int BIAS_TILES16_VD = 8 * 16 + 17 + 8 + 1;     // 154 tiles of 16 floats
+constexpr int BIAS_TILES16_NOVD = 8 * 16 + 1;            // 129
+constexpr int BIAS16_TILE_BYTES = 16 * 4;
+constexpr int bias16_block_bytes(bool vd) { return ((vd ? BIAS_TILES16_VD : BIAS_TILES16_NOVD) * BIAS16_TILE_BYTES + 127) / 128 * 128; }
+static_assert(pad_to_stage(FRAGS16_VD) == FRAGS_BF16_VD && pad_to_stage(FRAGS16_NOVD) == FRAGS_BF16_NOVD, "same stream length");
 
 static_assert(FRAGS_BF16_VD % STAGE_FRAGS == 0 && FRAGS_BF16_NOVD % STAGE_FRAGS == 0, "stage-aligned");
 static_assert(FRAGS_F32_VD % STAGE_FRAGS == 0 && FRAGS_F32_NOVD % STAGE_FRAGS == 0, "stage-aligned");

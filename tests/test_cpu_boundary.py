@@ -78,8 +78,10 @@ def test_packed_sizes_host_only():
     frag, bias = 1024, 128
     scales = 64          # pack-time scratch behind the bias block
     rowsums = 11 * 256 * 2 * 4          # pack-time scratch of the bf16 stream
-    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 1) == 1184 * frag + 78 * bias + scales + rowsums
-    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 0) == 976 * frag + 65 * bias + scales + rowsums
+    # bf16: the 32x32x16 stream the training kernels read, then the 16x16x32 stream of the inference kernel with its
+    # own bias tiles (154 / 129 tiles of 16 floats, padded to 128 bytes)
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 1) == 1184 * frag + 78 * bias + scales + rowsums + 1184 * frag + 9856
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 0) == 976 * frag + 65 * bias + scales + rowsums + 976 * frag + 8320
     assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 1) == 2368 * frag + 78 * bias + scales
     assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 0) == 1952 * frag + 65 * bias + scales
 

@@ -25,7 +25,7 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "mlp_" not in k: continue
+        if "mlp_" not in k and "mlp16_" not in k: continue
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[k][row["Counter_Name"]] += 1
 with open(out + "/summary.txt", "w") as fo:
     for k in agg:
