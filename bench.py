@@ -318,7 +318,7 @@ def mlp_roofline(events, precision, dt, n_rays, traffic):
     """MFMA roofline of the network kernel from the HIP events of its launches: the largest launches (the fine pass)
     carry `achieved`; algorithmic FLOPs = samples x 1 186 816."""
     peak = PEAK_TFLOPS[precision]
-    kname = "mlp_%s_kernel" % ("bf16" if precision == "bf16" else "f32")
+    kname = "mlp16_bf16_kernel" if precision == "bf16" else "mlp_f32_kernel"
     ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
     flops = [n * FLOP_PER_SAMPLE for _, _, n in events]
     big = [(m, f) for m, f in zip(ms, flops) if f == max(flops)]

@@ -726,6 +726,7 @@ extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewd
     a.n_stages = frag_total(precision, use_viewdirs) / STAGE_FRAGS;
     a.n_bias_tiles = use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD;
     a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
+    set_sample_divisor(a);
     a.tape = nullptr;
     const int per_tile = precision == NERF_PREC_BF16 ? 256 : 128;
     const long long n_tiles = (M + per_tile - 1) / per_tile;

@@ -63,6 +63,85 @@ __device__ __forceinline__ void encode_raw16(const RawIn& r, int g, float (&pe)[
     if (VD) encode_view16(r.v[0], r.v[1], r.v[2], g, vw);
 }
 
+// ---- raw inputs through LDS ------------------------------------------------------------------------------------------
+// The inputs of the NEXT pass are requested by LDS-DMA into a per-wave staging block [field 10][sample 64] (fields:
+// origin 3, direction 3, view direction 3, depth) and read back with ds_read at the top of that pass.  Loads into
+// registers would do, but the compiler cannot see the LDS-DMA of the weight ring in its vmcnt bookkeeping and guards
+// their first use with waits that drain the whole ring and the newest requests (4 k of 102 k cycles per pass).
+// Done by hand the count is exact: NIN vector-memory instructions per pass, in every mode, which the next four
+// stage hand-overs of the ring add to what may stay in flight (Pipe::advance_extra).
+constexpr int IN_FIELDS = 10;
+constexpr int IN_WAVE_BYTES = IN_FIELDS * 64 * 4;
+constexpr int IN_STAGE_BYTES = 4 * IN_WAVE_BYTES;
+constexpr int LDS16_BYTES = LDS_BYTES + IN_STAGE_BYTES;
+template <bool VD> constexpr int nin() { return VD ? 10 : 7; }
+
+#define NERF_IN_FIRST(va) "s_mov_b32 m0, %[base]\n\ts_nop 0\n\tglobal_load_lds_dword " va ", off\n\t"
+#define NERF_IN_NEXT(va, inc, off) "s_add_u32 m0, m0, " #inc "\n\ts_nop 0\n\tglobal_load_lds_dword " va ", off offset:" #off "\n\t"
+// field j of lane l lands at base + 256 j + 4 l: the LDS address is M0 + instruction offset + 4 l and the same offset
+// is added to the memory address, hence the uneven M0 steps
+template <bool VD>
+__device__ __forceinline__ void request_inputs(const MlpArgs& a, unsigned m, unsigned wave_block_lds_addr) {
+    const unsigned ray = sample_ray(a, m);
+    const unsigned base = __builtin_amdgcn_readfirstlane(wave_block_lds_addr);
+    unsigned keep;
+    if (a.mode == NERF_IN_RAYS) {
+        const unsigned long long row = reinterpret_cast<unsigned long long>(a.in0) + (unsigned long long)ray * (unsigned)a.ray_cols * 4ull;
+        const unsigned long long zz = reinterpret_cast<unsigned long long>(a.in1) + (unsigned long long)m * 4ull;
+        if (VD)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %[keep], m0\n\t"
+                         NERF_IN_FIRST("%[row]") NERF_IN_NEXT("%[row]", 252, 4) NERF_IN_NEXT("%[row]", 252, 8)
+                         NERF_IN_NEXT("%[row]", 252, 12) NERF_IN_NEXT("%[row]", 252, 16) NERF_IN_NEXT("%[row]", 252, 20)
+                         NERF_IN_NEXT("%[row]", 244, 32) NERF_IN_NEXT("%[row]", 252, 36) NERF_IN_NEXT("%[row]", 252, 40)
+                         NERF_IN_NEXT("%[zz]", 296, 0)
+                         "s_mov_b32 m0, %[keep]"
+                         : [keep] "=&s"(keep) : [row] "v"(row), [zz] "v"(zz), [base] "s"(base) : "memory", "scc");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %[keep], m0\n\t"
+                         NERF_IN_FIRST("%[row]") NERF_IN_NEXT("%[row]", 252, 4) NERF_IN_NEXT("%[row]", 252, 8)
+                         NERF_IN_NEXT("%[row]", 252, 12) NERF_IN_NEXT("%[row]", 252, 16) NERF_IN_NEXT("%[row]", 252, 20)
+                         NERF_IN_NEXT("%[zz]", 1044, 0)
+                         "s_mov_b32 m0, %[keep]"
+                         : [keep] "=&s"(keep) : [row] "v"(row), [zz] "v"(zz), [base] "s"(base) : "memory", "scc");
+    } else {
+        // NERF_IN_POINTS: origin = point, direction and depth are zero (not read back); their slots are filled by
+        // repeats of the first load so that the instruction count is the same in both modes
+        const unsigned long long pt = reinterpret_cast<unsigned long long>(a.in0) + (unsigned long long)m * 12ull;
+        const unsigned long long vd = VD ? reinterpret_cast<unsigned long long>(a.in1) + (unsigned long long)ray * 12ull : pt;
+        if (VD)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %[keep], m0\n\t"
+                         NERF_IN_FIRST("%[pt]") NERF_IN_NEXT("%[pt]", 252, 4) NERF_IN_NEXT("%[pt]", 252, 8)
+                         NERF_IN_NEXT("%[pt]", 264, 0) NERF_IN_NEXT("%[pt]", 256, 0) NERF_IN_NEXT("%[pt]", 256, 0)
+                         NERF_IN_NEXT("%[vd]", 256, 0) NERF_IN_NEXT("%[vd]", 252, 4) NERF_IN_NEXT("%[vd]", 252, 8)
+                         NERF_IN_NEXT("%[pt]", 264, 0)
+                         "s_mov_b32 m0, %[keep]"
+                         : [keep] "=&s"(keep) : [pt] "v"(pt), [vd] "v"(vd), [base] "s"(base) : "memory", "scc");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %[keep], m0\n\t"
+                         NERF_IN_FIRST("%[pt]") NERF_IN_NEXT("%[pt]", 252, 4) NERF_IN_NEXT("%[pt]", 252, 8)
+                         NERF_IN_NEXT("%[pt]", 264, 0) NERF_IN_NEXT("%[pt]", 256, 0) NERF_IN_NEXT("%[pt]", 256, 0)
+                         NERF_IN_NEXT("%[pt]", 1024, 0)
+                         "s_mov_b32 m0, %[keep]"
+                         : [keep] "=&s"(keep) : [pt] "v"(pt), [base] "s"(base) : "memory", "scc");
+    }
+}
+#undef NERF_IN_FIRST
+#undef NERF_IN_NEXT
+
+// the staged inputs of sample s (0..63) of the wave
+template <bool VD>
+__device__ __forceinline__ void read_inputs(const float* block, int s, bool rays_mode, RawIn& r) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.o[k] = block[k * 64 + s];
+        const float d = block[(3 + k) * 64 + s];
+        r.d[k] = rays_mode ? d : 0.0f;
+        r.v[k] = VD ? block[(6 + k) * 64 + s] : 0.0f;
+    }
+    const float z = block[9 * 64 + s];
+    r.z = rays_mode ? z : 0.0f;
+}
+
 // NERF_IN_FEATURES: the caller supplies the encodings; pick this lane's k-slots out of the row.
 template <bool VD>
 __device__ __forceinline__ void load_features16(const MlpArgs& a, unsigned m, int g, float (&pe)[16], float (&vw)[8]) {
@@ -105,8 +184,10 @@ __device__ __forceinline__ void epi_slice16(const f32x4v (&accp)[NCT], const Pen
 // previous tile (accumulators accp) is issued in the MFMA gaps of k-steps 1..EPI_N.  `early`: this tile reads, at
 // its last hidden k-step, what that epilogue writes (first tile of a layer), so the epilogue must be done two
 // k-steps before the end.
-template <int KPE, int KH, int KVW, bool early>
-__device__ __forceinline__ void tile16(Stream& st, int pos, int g, int bias_next_idx, f32x4v& bias,
+// `staged`: raw-input requests of this pass (NIN of them, issued before position 0) may still be in flight; the first
+// four stage hand-overs of the pass allow for them.
+template <int KPE, int KH, int KVW, bool early, int NIN>
+__device__ __forceinline__ void tile16(Stream& st, int pos, int g, bool staged, int bias_next_idx, f32x4v& bias,
                                        const u32x4 (*pe)[NCT], const u32x4 (*hin)[NCT], const u32x4 (*vw)[NCT],
                                        f32x4v (&acc)[NCT], const f32x4v (&accp)[NCT], const Pending& prev) {
     constexpr int KS = KPE + KH + KVW;
@@ -115,7 +196,10 @@ __device__ __forceinline__ void tile16(Stream& st, int pos, int g, int bias_next
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int k = pos + s;
-        st.tick(k);
+        if ((k & (STAGE_FRAGS - 1)) == STAGE_FRAGS / 2) {
+            if (k < 4 * STAGE_FRAGS && staged) st.p.template advance_extra<NIN>();
+            else st.p.advance();
+        }
         __builtin_amdgcn_sched_barrier(0);
         st.fetch(k + PF);
         if (s == KS / 2) bias_next = bias16(st.p.lds, bias_next_idx, g);
@@ -146,15 +230,15 @@ __device__ __forceinline__ void tile16(Stream& st, int pos, int g, int bias_next
 // NT tiles of one layer.  Tile number bt of the pass accumulates into accs[bt & 1]; tile t of the layer goes to dwords
 // 2 (t & 1), 2 (t & 1) + 1 of the quads hout[t >> 1][ct].  `pend` describes the tile that ran before this layer on
 // entry and this layer's last tile on return.
-template <int NT, int KPE, int KH, int KVW>
-__device__ __forceinline__ void layer16(Stream& st, int& pos, int& bt, int n_bias_tiles, int g, f32x4v& bias,
+template <int NT, int KPE, int KH, int KVW, int NIN>
+__device__ __forceinline__ void layer16(Stream& st, int& pos, int& bt, int n_bias_tiles, int g, bool staged, f32x4v& bias,
                                         const u32x4 (*pe)[NCT], const u32x4 (*hin)[NCT], const u32x4 (*vw)[NCT],
                                         f32x4v (&accs)[2][NCT], Pending& pend, u32x4 (*hout)[NCT], bool relu, bool convert) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int nb = (bt + 1) % n_bias_tiles;
-        if (t == 0) tile16<KPE, KH, KVW, true>(st, pos, g, nb, bias, pe, hin, vw, accs[bt & 1], accs[(bt & 1) ^ 1], pend);
-        else tile16<KPE, KH, KVW, false>(st, pos, g, nb, bias, pe, hin, vw, accs[bt & 1], accs[(bt & 1) ^ 1], pend);
+        if (t == 0) tile16<KPE, KH, KVW, true, NIN>(st, pos, g, staged, nb, bias, pe, hin, vw, accs[bt & 1], accs[(bt & 1) ^ 1], pend);
+        else tile16<KPE, KH, KVW, false, NIN>(st, pos, g, staged, nb, bias, pe, hin, vw, accs[bt & 1], accs[(bt & 1) ^ 1], pend);
         pend = Pending{hout + (t >> 1), 2 * (t & 1), relu, convert};
         pos += KPE + KH + KVW;
         bt += 1;
@@ -164,7 +248,7 @@ __device__ __forceinline__ void layer16(Stream& st, int& pos, int& bt, int n_bia
 template <bool VD, int OUT_CH>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp16_bf16_kernel(MlpArgs a) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS16_BYTES];
     Stream st;
     pipe_start(st.p, a, lds);
     st.slot0 = 0;
@@ -179,16 +263,16 @@ void mlp16_bf16_kernel(MlpArgs a) {
     for (int k = 0; k < PF; ++k) st.fetch(k);
     f32x4v bias = bias16(st.p.lds, 0, g);
 
-    // raw inputs are fetched one whole pass ahead (one wave per SIMD: nothing else hides the latency)
-    const bool feat_mode = a.mode == NERF_IN_FEATURES;
+    // raw inputs are requested one whole pass ahead (one wave per SIMD: nothing else hides the latency)
+    const bool feat_mode = a.mode == NERF_IN_FEATURES, rays_mode = a.mode == NERF_IN_RAYS;
+    const bool staged = !feat_mode;
     const unsigned Mu = (unsigned)a.M;
-    RawIn nxt[NCT];
-    if (!feat_mode && (long long)blockIdx.x < n_tiles) {
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const unsigned m = (unsigned)blockIdx.x * 256u + wave * 64 + ct * 16 + c;
-            fetch_raw<VD>(a, m < Mu ? m : Mu - 1, nxt[ct]);
-        }
+    const float* in_block = reinterpret_cast<const float*>(lds + LDS_BYTES + wave * IN_WAVE_BYTES);
+    const unsigned in_block_addr = (unsigned)(size_t)(lds_ptr_t)(lds + LDS_BYTES) + wave * IN_WAVE_BYTES;
+    if (staged) {
+        const unsigned m = (unsigned)blockIdx.x * 256u + wave * 64 + lane;
+        request_inputs<VD>(a, m < Mu ? m : Mu - 1, in_block_addr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // once per launch: the first pass has nothing to hide it under
     }
 
 #ifdef NERF_EXP_STAMP
@@ -197,22 +281,17 @@ void mlp16_bf16_kernel(MlpArgs a) {
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         NERF_STAMP(t0)
         u32x4 pe[2][NCT], vw[1][NCT];
-        RawIn cur[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) cur[ct] = nxt[ct];
-        if (!feat_mode && tile + gridDim.x < n_tiles) {
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const unsigned m = (unsigned)(tile + gridDim.x) * 256u + wave * 64 + ct * 16 + c;
-                fetch_raw<VD>(a, m < Mu ? m : Mu - 1, nxt[ct]);
-            }
-        }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             const unsigned m = (unsigned)tile * 256u + wave * 64 + ct * 16 + c;
             float pv[16], vv[8];
-            if (feat_mode) load_features16<VD>(a, m < Mu ? m : Mu - 1, g, pv, vv);
-            else encode_raw16<VD>(cur[ct], g, pv, vv);
+            if (feat_mode) {
+                load_features16<VD>(a, m < Mu ? m : Mu - 1, g, pv, vv);
+            } else {
+                RawIn cur;
+                read_inputs<VD>(in_block, ct * 16 + c, rays_mode, cur);
+                encode_raw16<VD>(cur, g, pv, vv);
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -222,6 +301,11 @@ void mlp16_bf16_kernel(MlpArgs a) {
                 for (int j = 0; j < 4; ++j) vw[0][ct][j] = pack_pair(vv[2 * j], vv[2 * j + 1], false);
             }
         }
+        if (staged) {
+            // always issued, so that the count the ring's waits allow for is exact: past the end, the last sample again
+            const unsigned long long mn = (unsigned long long)(tile + gridDim.x) * 256ull + wave * 64 + lane;
+            request_inputs<VD>(a, mn < Mu ? (unsigned)mn : Mu - 1, in_block_addr);
+        }
 
         NERF_STAMP(t1)
         u32x4 A[8][NCT], B[8][NCT];     // the 256 features of a layer's input / output as 8 k-step operands
@@ -229,7 +313,7 @@ void mlp16_bf16_kernel(MlpArgs a) {
         Pending pend{A, 0, false, false};
         int pos = 0, bt = 0;
 #define NERF_L16(NT, KPE, KH, KVW, hin, hout, relu, conv) \
-    layer16<NT, KPE, KH, KVW>(st, pos, bt, NB, g, bias, pe, hin, vw, accs, pend, hout, relu, conv)
+    layer16<NT, KPE, KH, KVW, nin<VD>()>(st, pos, bt, NB, g, staged, bias, pe, hin, vw, accs, pend, hout, relu, conv)
         NERF_L16(16, 2, 0, 0, A, A, true, true);      // L0: pe -> A
         NERF_L16(16, 0, 8, 0, A, B, true, true);      // L1
         NERF_L16(16, 0, 8, 0, B, A, true, true);      // L2

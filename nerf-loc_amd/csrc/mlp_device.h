@@ -28,7 +28,9 @@ static_assert(PREFETCH * 4 <= 63, "vmcnt is a 6-bit counter");
 
 #define NERF_STR2(x) #x
 #define NERF_STR(x) NERF_STR2(x)
-#if NERF_PREFETCH == 3
+#if defined(NERF_EXP_HALFDMA)
+#define NERF_VMCNT_KEEP "8"
+#elif NERF_PREFETCH == 3
 #define NERF_VMCNT_KEEP "12"
 #elif NERF_PREFETCH == 4
 #define NERF_VMCNT_KEEP "16"
@@ -52,7 +54,23 @@ struct MlpArgs {
     long long M;                   // samples
     float* out;
     unsigned char* tape;           // bf16 training forward only (train_bf16.h)
+    // sample index / S without a division (mlp16.h): exact for indices < 2^31, set by set_sample_divisor()
+    unsigned div_magic;
+    int div_shift;
 };
+
+// n / d for n < 2^31 as (n * magic) >> (31 + l), l = ceil(log2 d), magic = floor(2^(31+l) / d) + 1 < 2^32: the error
+// magic * d - 2^(31+l) is at most d, and n * d < 2^(31+l) for every n < 2^31, so the quotient is exact.
+inline void set_sample_divisor(MlpArgs& a) {
+    const unsigned d = (unsigned)a.S;
+    int l = 0;
+    while ((1ull << l) < d) ++l;
+    a.div_magic = (unsigned)((1ull << (31 + l)) / d + 1ull);
+    a.div_shift = l;
+}
+__device__ __forceinline__ unsigned sample_ray(const MlpArgs& a, unsigned m) {
+    return a.div_shift == 0 ? m : (__umulhi(m, a.div_magic) >> (a.div_shift - 1));
+}
 
 // ------------------------------------------------------------------------------------------
 // weight stream: LDS ring fed by LDS-DMA
@@ -90,8 +108,10 @@ struct Pipe {
             "s_nop 0\n\t"
             "global_load_lds_dwordx4 %1, %3\n\t"
             "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+#ifndef NERF_EXP_HALFDMA    // timing experiment only (results are garbage): half the bytes and instructions
             "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
             "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+#endif
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
             : "v"(src_off), "s"(m0v), "s"(gs)
@@ -107,6 +127,16 @@ struct Pipe {
 #ifndef NERF_EXP_NOBARRIER
         __builtin_amdgcn_s_barrier();
 #endif
+        asm volatile("" ::: "memory");
+    }
+    // advance() while EXTRA younger vector-memory operations of this wave (issued after the stage that has to become
+    // visible) are in flight as well: vmcnt counts in issue order, so they are added to what may stay outstanding
+    template <int EXTRA>
+    __device__ __forceinline__ void advance_extra() {
+        static_assert(PREFETCH * 4 + EXTRA <= 63, "vmcnt is a 6-bit counter");
+        issue();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCH * 4 + EXTRA) : "memory");
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void next_stage() {

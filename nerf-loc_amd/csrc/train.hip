@@ -463,6 +463,7 @@ extern "C" int nerf_mlp_forward_train(const void* packed, int precision, int use
     a.n_stages = (use_viewdirs ? FRAGS_F32_VD : FRAGS_F32_NOVD) / STAGE_FRAGS;
     a.n_bias_tiles = use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD;
     a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
+    set_sample_divisor(a);
     a.tape = nullptr;
     hipStream_t st = as_stream(stream);
     if (precision == NERF_PREC_BF16) {

@@ -27,7 +27,7 @@ with open(out + "/kernel_stats.txt", "w") as fo:
     for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
         fo.write("%-64s %6d %12.3f %10.4f %10.4f %10.4f %6.2f%%\n" % (k[:64], len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot))
     for k, v in per.items():
-        if "mlp_" in k and "kernel" in k and "pack" not in k:
+        if ("mlp_" in k or "mlp16_" in k) and "kernel" in k and "pack" not in k:
             big = [x for x in v if x > 0.5 * max(v)]
             small = [x for x in v if x <= 0.5 * max(v)]
             fo.write("\n%s\n  fine-pass launches (192 samples/ray): %d, avg %.4f ms\n  coarse-pass launches (64 samples/ray): %d, avg %.4f ms\n"
@@ -46,7 +46,7 @@ with open(out + "/traffic.txt", "w") as fo:
         fo.write(k[:100] + "\n")
         for c, v in d.items():
             fo.write("  %-12s launches %4d  max %14.1f  min %14.1f  mean %14.1f\n" % (c, len(v), max(v), min(v), sum(v) / len(v)))
-        if "mlp_" in k and "pack" not in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        if ("mlp_" in k or "mlp16_" in k) and "pack" not in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             # largest launches = fine pass; FETCH_SIZE x2 (gfx950 tallies 128-B read requests as 64 B), WRITE_SIZE as is
             fs = [x for x in d["FETCH_SIZE"] if x > 0.5 * max(d["FETCH_SIZE"])]
             ws = [x for x in d["WRITE_SIZE"] if x > 0.5 * max(d["WRITE_SIZE"])]
