@@ -238,14 +238,14 @@ def make_workload(name, precision, args, rank, world, device):
         w.update(n_rays=n_rays, total_rays=n_rays * world, flop_per_ray=64 * FLOP_PER_SAMPLE,
                  parallelism="objects round-robin x%d, no collective" % world,
                  desc=("BASELINE configs[3]: %d objects/GPU x 2 focal lengths x 8 poses x %dx%d, 64 samples, coarse net, "
-                       "rgb + depth + raw volume kept on device, %s-MFMA mode" % (n_obj, H, W, precision)))
+                       "rgb + depth + raw volume kept on device, one network launch per field of view, %s-MFMA mode" % (n_obj, H, W, precision)))
 
         def step():
             out = None
-            for kw in objs:
-                for Kx in (K, Kc):
-                    rgbs, disps, raws, depths = nerf_utils.render_path_device(poses, [H, W, float(Kx[0][0])], Kx, kw)
-                    out = rgbs.reshape(-1, 3)
+            for Kx in (K, Kc):       # both fields of view; all objects of the rank as ONE network launch each
+                rgbs, disps, raws, depths = nerf_utils.render_path_device_objects([poses] * n_obj, [H, W, float(Kx[0][0])],
+                                                                                  Kx, objs)
+                out = rgbs.reshape(-1, 3)
             return out
     else:
         from nerf_loc_amd import helpers, train

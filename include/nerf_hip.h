@@ -41,8 +41,8 @@ extern "C" {
                               /* in registers, never written to memory (render_rays)               */
 
 /* Version of this interface (2: the training entry points take a `precision` argument; 3: adds
- * nerf_mlp_backward_static). */
-#define NERF_HIP_ABI_VERSION 3
+ * nerf_mlp_backward_static; 4: adds nerf_mlp_forward_objects). */
+#define NERF_HIP_ABI_VERSION 4
 int nerf_hip_abi_version(void);
 const char* nerf_last_error(void);
 
@@ -78,6 +78,13 @@ int nerf_z_vals(const float* rays, int ray_cols, int R, int S, const float* t_va
 int nerf_embed(const float* x, long long M, int multires, int include_input, float* out,
                void* stream);
 
+/* How many NaN / Inf values each of up to 16 tensors holds, in one launch: the census behind the reference's
+ * "! [Numerical Error] ... contains nan or inf." warnings (run_nerf.py:420-422; nerf_utils.py:336-340 checks every
+ * render).  ptrs_host / numel_host: HOST arrays of device pointers and element counts; counts_dev: DEVICE int32
+ * [n_tensors], zeroed and filled by the call.                                                               */
+int nerf_count_nonfinite(int n_tensors, const float* const* ptrs_host, const long long* numel_host,
+                         int* counts_dev, void* stream);
+
 /* ---- network ---------------------------------------------------------------------------
  * NeRF(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4]) of run_nerf_helpers.py:67-119,
  * together with the positional encoding (run_nerf_helpers.py:15-63) and the flatten /
@@ -101,6 +108,18 @@ int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs, int output
 int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int output_ch,
                      int input_mode, const float* in0, const float* in1,
                      int R, int S, int ray_cols, float* raw_out, void* stream);
+
+/* run_network for SEVERAL independent networks in one launch: the multi-NeRF workload (one network per object,
+ * run_multi_nerf.py:560-572) as NeRF-Loc consumes it, a batch of scans each rendered with its own network
+ * (model_3detr.py:619-724).  The flat batch holds n_objects equal parts: rays [o R/n, (o+1) R/n) (and their samples)
+ * are evaluated with network o.  packed_table_dev: DEVICE array of n_objects pointers to packed streams
+ * (nerf_mlp_pack; same precision, use_viewdirs and output_ch for all).  R must divide evenly and the samples per
+ * network, R/n * S, must be a multiple of 256 (NERF_PREC_BF16) or 128 (NERF_PREC_F32); n_objects at most the number
+ * of compute units.  Every other argument as for nerf_mlp_forward; results are bit-identical to n_objects separate
+ * nerf_mlp_forward calls.                                                                                   */
+int nerf_mlp_forward_objects(const void* const* packed_table_dev, int n_objects, int precision, int use_viewdirs,
+                             int output_ch, int input_mode, const float* in0, const float* in1,
+                             int R, int S, int ray_cols, float* raw_out, void* stream);
 
 /* ---- compositing -----------------------------------------------------------------------
  * raw2outputs, run_nerf.py:268-311 (and nerf_utils.py:344-395).  raw [R,S,raw_ch] (raw_ch 4

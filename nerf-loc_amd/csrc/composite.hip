@@ -119,6 +119,126 @@ __global__ __launch_bounds__(256) void raw2outputs_kernel(
     }
 }
 
+// Rays of at most 64 samples (the coarse pass): a ray is taken by ONE 16-lane row of the wavefront, four consecutive
+// samples per lane, so a wave works on four rays at once and every scan / sum is four DPP row shifts: no cross-row
+// traffic, no LDS.  Loads are 16-byte (raw: one float4 per sample, z: one float4 per lane) when the row length allows.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 CTRL, 0xf, 0xf, false));
+}
+constexpr int DPP_ROW_SHR = 0x110, DPP_ROW_SHL = 0x100;
+__device__ __forceinline__ float row_sum_to_last(float s) {      // lane 15 of each row ends up with the row's sum
+    s += dpp_f<DPP_ROW_SHR + 1>(0.f, s);
+    s += dpp_f<DPP_ROW_SHR + 2>(0.f, s);
+    s += dpp_f<DPP_ROW_SHR + 4>(0.f, s);
+    s += dpp_f<DPP_ROW_SHR + 8>(0.f, s);
+    return s;
+}
+
+template <int RAW_CH, bool VEC>
+__global__ __launch_bounds__(256) void raw2outputs_row_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ d_ptr,
+    int d_stride, const float* __restrict__ noise, int R, int S, int white_bkgd,
+    float* __restrict__ rgb_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
+    float* __restrict__ depth_out, float* __restrict__ weights_out) {
+    const int j = threadIdx.x & 15;                                   // lane in the row: samples 4 j .. 4 j + 3
+    const long long ray_u = (long long)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const bool ray_ok = ray_u < R;
+    const size_t ray = ray_ok ? (size_t)ray_u : (size_t)(R - 1);      // idle rows redo the last ray and store nothing
+    const float* zr = z_vals + ray * S;
+    const float* rr = raw + ray * S * RAW_CH;
+    const float* nr = noise ? noise + ray * S : nullptr;
+    const float* dp = d_ptr + ray * d_stride;
+    const float dx = dp[0], dy = dp[1], dz = dp[2];
+    const float dnorm = sqrtf(fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz)));
+
+    float r0[4], r1[4], r2[4], r3[4], z[5], nz[4];
+    const int i0 = 4 * j;
+    if (VEC) {          // S % 4 == 0, RAW_CH == 4, 16-byte aligned bases: whole quads are valid or not
+        const int q = i0 < S ? i0 : S - 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 v = reinterpret_cast<const float4*>(rr)[q + k];
+            r0[k] = v.x; r1[k] = v.y; r2[k] = v.z; r3[k] = v.w;
+        }
+        const float4 zq = *reinterpret_cast<const float4*>(zr + q);
+        z[0] = zq.x; z[1] = zq.y; z[2] = zq.z; z[3] = zq.w;
+        if (nr) { const float4 nq = *reinterpret_cast<const float4*>(nr + q); nz[0] = nq.x; nz[1] = nq.y; nz[2] = nq.z; nz[3] = nq.w; }
+        else { nz[0] = nz[1] = nz[2] = nz[3] = 0.f; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ic = i0 + k < S ? i0 + k : S - 1;
+            const float* v = rr + (size_t)ic * RAW_CH;
+            r0[k] = v[0]; r1[k] = v[1]; r2[k] = v[2]; r3[k] = v[3];
+            z[k] = zr[ic];
+            nz[k] = nr ? nr[ic] : 0.f;
+        }
+    }
+    // the depth after this lane's four: the next lane's first (row shift left by one; the last lane keeps its own)
+    z[4] = dpp_f<DPP_ROW_SHL + 1>(z[3], z[0]);
+
+    float alpha[4], om[4], c0[4], c1[4], c2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k;
+        const bool valid = i < S;
+        alpha[k] = 0.f; c0[k] = c1[k] = c2[k] = 0.f;
+        if (valid) {
+            const float dist = fmul((i + 1 < S) ? fsub(z[k + 1], z[k]) : 1e10f, dnorm);
+            const float sig = fmaxf(fadd(r3[k], nz[k]), 0.0f);
+            alpha[k] = fsub(1.0f, fast_exp_neg(fmul(sig, dist)));
+            c0[k] = fast_sigmoid(r0[k]);
+            c1[k] = fast_sigmoid(r1[k]);
+            c2[k] = fast_sigmoid(r2[k]);
+        }
+        om[k] = fadd(fsub(1.0f, alpha[k]), 1e-10f);
+    }
+    // exclusive transmittance: product over the lane's earlier samples times the product over all earlier lanes
+    const float p1 = om[0], p2 = p1 * om[1], p3 = p2 * om[2], p4 = p3 * om[3];
+    float incl = p4;
+    incl *= dpp_f<DPP_ROW_SHR + 1>(1.f, incl);
+    incl *= dpp_f<DPP_ROW_SHR + 2>(1.f, incl);
+    incl *= dpp_f<DPP_ROW_SHR + 4>(1.f, incl);
+    incl *= dpp_f<DPP_ROW_SHR + 8>(1.f, incl);
+    const float before = dpp_f<DPP_ROW_SHR + 1>(1.f, incl);
+    const float T[4] = {before, before * p1, before * p2, before * p3};
+    float w[4], s_r = 0.f, s_g = 0.f, s_b = 0.f, s_depth = 0.f, s_acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        w[k] = alpha[k] * T[k];
+        s_r += w[k] * c0[k]; s_g += w[k] * c1[k]; s_b += w[k] * c2[k];
+        s_depth += w[k] * z[k];
+        s_acc += w[k];
+    }
+    if (weights_out && ray_ok) {
+        float* wo = weights_out + ray * S;
+        if (VEC) { if (i0 < S) *reinterpret_cast<float4*>(wo + i0) = make_float4(w[0], w[1], w[2], w[3]); }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i0 + k < S) wo[i0 + k] = w[k];
+        }
+    }
+    s_r = row_sum_to_last(s_r); s_g = row_sum_to_last(s_g); s_b = row_sum_to_last(s_b);
+    s_depth = row_sum_to_last(s_depth); s_acc = row_sum_to_last(s_acc);
+    if (j == 15 && ray_ok) {
+        if (rgb_out) {
+            const float bg = white_bkgd ? fsub(1.0f, s_acc) : 0.0f;
+            rgb_out[ray * 3 + 0] = s_r + bg;
+            rgb_out[ray * 3 + 1] = s_g + bg;
+            rgb_out[ray * 3 + 2] = s_b + bg;
+        }
+        if (disp_out) {
+            const float q = fdiv(s_depth, s_acc);
+            const float m = (q != q) ? q : fmaxf(1e-10f, q);
+            disp_out[ray] = fdiv(1.0f, m);
+        }
+        if (acc_out) acc_out[ray] = s_acc;
+        if (depth_out) depth_out[ray] = s_depth;
+    }
+}
+
 // Backward of raw2outputs.  The reference obtains it from autograd over run_nerf.py:268-311; here the
 // forward quantities are recomputed per ray and the chain rule is applied in closed form:
 //   c = sigmoid(raw_rgb), e = exp(-sigma dist), alpha = 1 - e, T_i = prod_{j<i} (1 - alpha_j + 1e-10), w = alpha T
@@ -245,7 +365,21 @@ extern "C" int nerf_raw2outputs(const float* raw, int raw_ch, const float* z_val
     if (raw_ch == 4) NERF_REQUIRE(((uintptr_t)raw & 15) == 0, "nerf_raw2outputs: raw must be 16-byte aligned");
     if (R == 0) return NERF_OK;
     const int nch = (S + 63) / 64;
-    const int rpw = nch == 1 ? 4 : nch == 2 ? 2 : 1;
+    if (nch == 1) {      // a 16-lane row per ray
+        const bool vec = raw_ch == 4 && S % 4 == 0 && ((uintptr_t)z_vals & 15) == 0 && (!noise || ((uintptr_t)noise & 15) == 0) &&
+                         (!weights || ((uintptr_t)weights & 15) == 0);
+        dim3 rgrid((R + 15) / 16), rblock(256);
+#define NERF_R2O_ROW(CH, V)                                                                                              \
+    hipLaunchKernelGGL((raw2outputs_row_kernel<CH, V>), rgrid, rblock, 0, as_stream(stream), raw, z_vals, d_ptr, d_stride, \
+                       noise, R, S, white_bkgd, rgb, disp, acc, depth, weights)
+        if (vec) NERF_R2O_ROW(4, true);
+        else if (raw_ch == 4) NERF_R2O_ROW(4, false);
+        else NERF_R2O_ROW(5, false);
+#undef NERF_R2O_ROW
+        NERF_LAUNCH_CHECK();
+        return NERF_OK;
+    }
+    const int rpw = nch == 2 ? 2 : 1;
     const int rays_per_block = 4 * rpw;
     dim3 grid((R + rays_per_block - 1) / rays_per_block), block(4 * WAVE);
 #define NERF_R2O_FWD(CH, n, q)                                                                                       \

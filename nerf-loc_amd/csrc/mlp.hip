@@ -214,25 +214,26 @@ template <bool VD, int OUT_CH>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp_f32_kernel(MlpArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    const TileWalk tw = tile_walk(a, (a.M + 127) / 128);
     Pipe p;
     pipe_start(p, a, lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, c = lane & 31;
-    const long long n_tiles = (a.M + 127) / 128;
 
     const bool feat_mode = a.mode == NERF_IN_FEATURES;
     const unsigned Mu = (unsigned)a.M;
     RawIn nxt;
-    if (!feat_mode && (long long)blockIdx.x < n_tiles) {
-        const unsigned m0 = (unsigned)blockIdx.x * 128u + wave * 32 + c;
+    if (!feat_mode && tw.first < tw.end) {
+        const unsigned m0 = (unsigned)(tw.base + tw.first) * 128u + wave * 32 + c;
         fetch_raw<VD>(a, m0 < Mu ? m0 : Mu - 1, nxt);
     }
 
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (long long t = tw.first; t < tw.end; t += tw.stride) {
+        const long long tile = tw.base + t;
         const unsigned m = (unsigned)tile * 128u + wave * 32 + c;
         const RawIn cur = nxt;
-        if (!feat_mode && tile + gridDim.x < n_tiles) {
-            const unsigned mn = (unsigned)(tile + gridDim.x) * 128u + wave * 32 + c;
+        if (!feat_mode && t + tw.stride < tw.end) {
+            const unsigned mn = (unsigned)(tile + tw.stride) * 128u + wave * 32 + c;
             fetch_raw<VD>(a, mn < Mu ? mn : Mu - 1, nxt);
         }
         float pe[32], vw[16];
@@ -698,29 +699,30 @@ extern "C" int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs,
     return NERF_OK;
 }
 
-extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int output_ch, int input_mode,
-                                const float* in0, const float* in1, int R, int S, int ray_cols, float* raw_out,
-                                void* stream) {
-    NERF_REQUIRE(packed && (R == 0 || (in0 && raw_out)), "nerf_mlp_forward: null pointer");
-    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_F32, "nerf_mlp_forward: unknown precision %d", precision);
-    NERF_REQUIRE(R >= 0 && S >= 1, "nerf_mlp_forward: bad shape R=%d S=%d", R, S);
-    if (use_viewdirs) NERF_REQUIRE(output_ch == 4, "nerf_mlp_forward: output_ch must be 4 with view directions");
-    else NERF_REQUIRE(output_ch == 4 || output_ch == 5, "nerf_mlp_forward: output_ch must be 4 or 5");
+static int mlp_forward_impl(const char* who, const void* packed, const void* const* table, int n_objects, int precision,
+                            int use_viewdirs, int output_ch, int input_mode, const float* in0, const float* in1, int R,
+                            int S, int ray_cols, float* raw_out, void* stream) {
+    NERF_REQUIRE((packed || table) && (R == 0 || (in0 && raw_out)), "%s: null pointer", who);
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_F32, "%s: unknown precision %d", who, precision);
+    NERF_REQUIRE(R >= 0 && S >= 1, "%s: bad shape R=%d S=%d", who, R, S);
+    if (use_viewdirs) NERF_REQUIRE(output_ch == 4, "%s: output_ch must be 4 with view directions", who);
+    else NERF_REQUIRE(output_ch == 4 || output_ch == 5, "%s: output_ch must be 4 or 5", who);
     switch (input_mode) {
-        case NERF_IN_FEATURES: NERF_REQUIRE(S == 1, "nerf_mlp_forward: feature input is flat (S = 1)"); break;
-        case NERF_IN_POINTS: NERF_REQUIRE(R == 0 || !use_viewdirs || in1, "nerf_mlp_forward: view directions missing"); break;
+        case NERF_IN_FEATURES: NERF_REQUIRE(S == 1, "%s: feature input is flat (S = 1)", who); break;
+        case NERF_IN_POINTS: NERF_REQUIRE(R == 0 || !use_viewdirs || in1, "%s: view directions missing", who); break;
         case NERF_IN_RAYS:
-            NERF_REQUIRE(R == 0 || in1, "nerf_mlp_forward: z_vals missing");
-            NERF_REQUIRE(ray_cols >= (use_viewdirs ? 11 : 8), "nerf_mlp_forward: rays need %d columns, got %d",
+            NERF_REQUIRE(R == 0 || in1, "%s: z_vals missing", who);
+            NERF_REQUIRE(ray_cols >= (use_viewdirs ? 11 : 8), "%s: rays need %d columns, got %d", who,
                          use_viewdirs ? 11 : 8, ray_cols);
             break;
-        default: NERF_REQUIRE(false, "nerf_mlp_forward: unknown input mode %d", input_mode);
+        default: NERF_REQUIRE(false, "%s: unknown input mode %d", who, input_mode);
     }
-    if (output_ch == 4) NERF_REQUIRE(((uintptr_t)raw_out & 15) == 0, "nerf_mlp_forward: raw_out must be 16-byte aligned");
-    NERF_REQUIRE(((uintptr_t)packed & 15) == 0, "nerf_mlp_forward: packed weights must be 16-byte aligned");
+    if (output_ch == 4) NERF_REQUIRE(((uintptr_t)raw_out & 15) == 0, "%s: raw_out must be 16-byte aligned", who);
+    NERF_REQUIRE(((uintptr_t)packed & 15) == 0, "%s: packed weights must be 16-byte aligned", who);
     const long long M = (long long)R * S;
     if (M == 0) return NERF_OK;
-    NERF_REQUIRE(M < (1ll << 31) - 512, "nerf_mlp_forward: at most 2^31 - 512 samples per launch, got %lld", M);
+    NERF_REQUIRE(M < (1ll << 31) - 512, "%s: at most 2^31 - 512 samples per launch, got %lld", who, M);
+    const int per_tile = precision == NERF_PREC_BF16 ? 256 : 128;
     MlpArgs a;
     a.packed = static_cast<const unsigned char*>(packed);
     a.n_stages = frag_total(precision, use_viewdirs) / STAGE_FRAGS;
@@ -728,12 +730,23 @@ extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewd
     a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
     set_sample_divisor(a);
     a.tape = nullptr;
-    const int per_tile = precision == NERF_PREC_BF16 ? 256 : 128;
+    a.table = nullptr; a.n_obj = 1; a.tiles_per_obj = 0; a.table_off = 0;
     const long long n_tiles = (M + per_tile - 1) / per_tile;
-    const int grid = (int)(n_tiles < cu_count() ? n_tiles : cu_count());
+    long long grid = n_tiles < cu_count() ? n_tiles : cu_count();
+    if (table) {
+        NERF_REQUIRE(n_objects >= 1 && R % n_objects == 0, "%s: %d rays do not split evenly over %d networks", who, R, n_objects);
+        const long long per_obj = M / n_objects;
+        NERF_REQUIRE(per_obj % per_tile == 0, "%s: samples per network (%lld) must be a multiple of %d", who, per_obj, per_tile);
+        NERF_REQUIRE(n_objects <= cu_count(), "%s: at most %d networks per launch, got %d", who, cu_count(), n_objects);
+        a.table = reinterpret_cast<const unsigned char* const*>(table);
+        a.n_obj = n_objects;
+        a.tiles_per_obj = per_obj / per_tile;
+        // a network is served by floor(CUs / networks) workgroups or one more (tile_walk), never by more than it has tiles
+        grid = a.tiles_per_obj * n_objects <= cu_count() ? a.tiles_per_obj * n_objects : cu_count();
+    }
     hipStream_t st = as_stream(stream);
     if (precision == NERF_PREC_BF16) {
-        a.packed += stream16_offset(use_viewdirs);
+        if (table) a.table_off = stream16_offset(use_viewdirs); else a.packed += stream16_offset(use_viewdirs);
         a.n_bias_tiles = ((use_viewdirs ? BIAS_TILES16_VD : BIAS_TILES16_NOVD) * 16 + 31) / 32;    // in units of 32 floats
         if (use_viewdirs) hipLaunchKernelGGL((m16::mlp16_bf16_kernel<true, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
         else if (output_ch == 4) hipLaunchKernelGGL((m16::mlp16_bf16_kernel<false, 4>), dim3(grid), dim3(MLP_THREADS), 0, st, a);
@@ -745,4 +758,20 @@ extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewd
     }
     NERF_LAUNCH_CHECK();
     return NERF_OK;
+}
+
+extern "C" int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int output_ch, int input_mode,
+                                const float* in0, const float* in1, int R, int S, int ray_cols, float* raw_out,
+                                void* stream) {
+    NERF_REQUIRE(packed, "nerf_mlp_forward: null pointer");
+    return mlp_forward_impl("nerf_mlp_forward", packed, nullptr, 1, precision, use_viewdirs, output_ch, input_mode, in0, in1,
+                            R, S, ray_cols, raw_out, stream);
+}
+
+extern "C" int nerf_mlp_forward_objects(const void* const* packed_table_dev, int n_objects, int precision, int use_viewdirs,
+                                        int output_ch, int input_mode, const float* in0, const float* in1, int R, int S,
+                                        int ray_cols, float* raw_out, void* stream) {
+    NERF_REQUIRE(packed_table_dev, "nerf_mlp_forward_objects: null pointer");
+    return mlp_forward_impl("nerf_mlp_forward_objects", nullptr, packed_table_dev, n_objects, precision, use_viewdirs, output_ch,
+                            input_mode, in0, in1, R, S, ray_cols, raw_out, stream);
 }

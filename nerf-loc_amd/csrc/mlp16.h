@@ -249,12 +249,12 @@ template <bool VD, int OUT_CH>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp16_bf16_kernel(MlpArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS16_BYTES];
+    const TileWalk tw = tile_walk(a, (a.M + 255) / 256);
     Stream st;
     pipe_start(st.p, a, lds);
     st.slot0 = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const long long n_tiles = (a.M + 255) / 256;
     constexpr int NB = VD ? BIAS_TILES16_VD : BIAS_TILES16_NOVD;
     constexpr int NFRAGS = VD ? FRAGS16_VD : FRAGS16_NOVD;
     constexpr int NPAD = VD ? FRAGS_BF16_VD : FRAGS_BF16_NOVD;      // stream length with the zero padding
@@ -270,15 +270,16 @@ void mlp16_bf16_kernel(MlpArgs a) {
     const float* in_block = reinterpret_cast<const float*>(lds + LDS_BYTES + wave * IN_WAVE_BYTES);
     const unsigned in_block_addr = (unsigned)(size_t)(lds_ptr_t)(lds + LDS_BYTES) + wave * IN_WAVE_BYTES;
     if (staged) {
-        const unsigned m = (unsigned)blockIdx.x * 256u + wave * 64 + lane;
-        request_inputs<VD>(a, m < Mu ? m : Mu - 1, in_block_addr);
+        const unsigned long long m = (unsigned long long)(tw.base + tw.first) * 256ull + wave * 64 + lane;
+        request_inputs<VD>(a, m < Mu ? (unsigned)m : Mu - 1, in_block_addr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // once per launch: the first pass has nothing to hide it under
     }
 
 #ifdef NERF_EXP_STAMP
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, acc_t[6] = {0, 0, 0, 0, 0, 0};
 #endif
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (long long t = tw.first; t < tw.end; t += tw.stride) {
+        const long long tile = tw.base + t;
         NERF_STAMP(t0)
         u32x4 pe[2][NCT], vw[1][NCT];
 #pragma unroll
@@ -303,7 +304,7 @@ void mlp16_bf16_kernel(MlpArgs a) {
         }
         if (staged) {
             // always issued, so that the count the ring's waits allow for is exact: past the end, the last sample again
-            const unsigned long long mn = (unsigned long long)(tile + gridDim.x) * 256ull + wave * 64 + lane;
+            const unsigned long long mn = (unsigned long long)(tile + tw.stride) * 256ull + wave * 64 + lane;
             request_inputs<VD>(a, mn < Mu ? (unsigned)mn : Mu - 1, in_block_addr);
         }
 

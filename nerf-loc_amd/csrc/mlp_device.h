@@ -54,6 +54,12 @@ struct MlpArgs {
     long long M;                   // samples
     float* out;
     unsigned char* tape;           // bf16 training forward only (train_bf16.h)
+    // several independent networks in one launch (nerf_mlp_forward_objects): DEVICE table of n_obj packed streams,
+    // network o owns tiles [o * tiles_per_obj, (o + 1) * tiles_per_obj); table == nullptr: the single stream `packed`
+    const unsigned char* const* table;
+    int n_obj;
+    long long tiles_per_obj;
+    size_t table_off;              // byte offset of the stream this kernel reads inside each packed buffer
     // sample index / S without a division (mlp16.h): exact for indices < 2^31, set by set_sample_divisor()
     unsigned div_magic;
     int div_shift;
@@ -153,6 +159,20 @@ struct Pipe {
         return lds + read_off + (pos & (STAGE_FRAGS - 1)) * FRAG_BYTES + lane16;
     }
 };
+
+// Which tiles a workgroup takes.  One network: tiles b, b + G, ... of all n_tiles (G workgroups).  Several networks:
+// workgroup b serves network b % n_obj for its whole life (so its weight ring never changes stream) and, as number
+// b / n_obj of the workgroups of that network, every stride-th of that network's tiles.
+struct TileWalk {
+    long long base, first, end, stride;      // tile = base + t, t = first, first + stride, ... < end
+};
+__device__ __forceinline__ TileWalk tile_walk(MlpArgs& a, long long n_tiles) {
+    if (!a.table) return TileWalk{0, (long long)blockIdx.x, n_tiles, (long long)gridDim.x};
+    const int obj = (int)(blockIdx.x % (unsigned)a.n_obj);
+    a.packed = a.table[obj] + a.table_off;
+    return TileWalk{obj * a.tiles_per_obj, (long long)(blockIdx.x / (unsigned)a.n_obj), a.tiles_per_obj,
+                    (long long)((gridDim.x - obj + a.n_obj - 1) / a.n_obj)};
+}
 
 __device__ __forceinline__ void pipe_start(Pipe& p, const MlpArgs& a, unsigned char* lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

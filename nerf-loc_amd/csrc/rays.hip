@@ -133,9 +133,72 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x,
     out[idx] = v;
 }
 
+// NaN / Inf census of up to CENSUS_MAX tensors in one launch (the check the reference makes key by key with
+// torch.isnan(...).any() / torch.isinf(...).any(), run_nerf.py:420-422, nerf_utils.py:336-340): streaming read,
+// one atomic per workgroup and tensor that has any.
+constexpr int CENSUS_MAX = 16;
+struct CensusArgs {
+    const float* p[CENSUS_MAX];
+    long long end[CENSUS_MAX];     // running end (elements) of tensor t in the concatenated index space
+    int n;
+    int* counts;
+};
+__global__ __launch_bounds__(256) void census_kernel(CensusArgs a) {
+    __shared__ int cnt[CENSUS_MAX];
+    if (threadIdx.x < CENSUS_MAX) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long long)gridDim.x * blockDim.x;
+    auto bad = [](float v) { return (int)((__float_as_uint(v) & 0x7f800000u) == 0x7f800000u); };
+    for (int t = 0; t < a.n; ++t) {                          // uniform loop: every workgroup sweeps every tensor
+        const float* p = a.p[t];
+        const long long n = a.end[t] - (t ? a.end[t - 1] : 0);
+        // 16-byte loads from the first aligned element on; the few elements in front and behind one by one
+        const long long head = ((16 - ((uintptr_t)p & 15)) & 15) / 4 < n ? ((16 - ((uintptr_t)p & 15)) & 15) / 4 : n;
+        const long long n4 = (n - head) / 4;
+        const float4* p4 = reinterpret_cast<const float4*>(p + head);
+        int local = 0;
+        for (long long i = tid; i < n4; i += 4 * nthr) {     // four independent loads in flight per lane
+            const long long i1 = i + nthr, i2 = i + 2 * nthr, i3 = i + 3 * nthr;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 q0 = p4[i], q1 = i1 < n4 ? p4[i1] : z, q2 = i2 < n4 ? p4[i2] : z, q3 = i3 < n4 ? p4[i3] : z;
+            local += bad(q0.x) + bad(q0.y) + bad(q0.z) + bad(q0.w) + bad(q1.x) + bad(q1.y) + bad(q1.z) + bad(q1.w) +
+                     bad(q2.x) + bad(q2.y) + bad(q2.z) + bad(q2.w) + bad(q3.x) + bad(q3.y) + bad(q3.z) + bad(q3.w);
+        }
+        if (tid < head) local += bad(p[tid]);
+        const long long tail0 = head + 4 * n4;
+        if (tid < n - tail0) local += bad(p[tail0 + tid]);
+        if (local) atomicAdd(&cnt[t], local);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.n && cnt[threadIdx.x]) atomicAdd(&a.counts[threadIdx.x], cnt[threadIdx.x]);
+}
+
 }  // namespace nerf
 
 using namespace nerf;
+
+extern "C" int nerf_count_nonfinite(int n_tensors, const float* const* ptrs_host, const long long* numel_host,
+                                    int* counts_dev, void* stream) {
+    NERF_REQUIRE(n_tensors >= 1 && n_tensors <= CENSUS_MAX, "nerf_count_nonfinite: 1..%d tensors per call, got %d", CENSUS_MAX, n_tensors);
+    NERF_REQUIRE(ptrs_host && numel_host && counts_dev, "nerf_count_nonfinite: null pointer");
+    CensusArgs a;
+    long long end = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+        NERF_REQUIRE(numel_host[t] >= 0 && (numel_host[t] == 0 || ptrs_host[t]), "nerf_count_nonfinite: tensor %d is null", t);
+        a.p[t] = ptrs_host[t];
+        end += numel_host[t];
+        a.end[t] = end;
+    }
+    a.n = n_tensors;
+    a.counts = counts_dev;
+    NERF_HIP_CHECK(hipMemsetAsync(counts_dev, 0, sizeof(int) * n_tensors, as_stream(stream)));
+    if (end == 0) return NERF_OK;
+    long long blocks = (end + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(census_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+}
 
 extern "C" int nerf_embed(const float* x, long long M, int multires, int include_input, float* out, void* stream) {
     NERF_REQUIRE(M == 0 || (x && out), "nerf_embed: null pointer");

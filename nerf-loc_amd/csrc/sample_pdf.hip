@@ -1,8 +1,8 @@
 // Hierarchical (inverse-CDF) sampling: sample_pdf (run_nerf_helpers.py:196-239) with the
 // mid-point, sort(cat) and z_std code around it in render_rays (run_nerf.py:397-401, 418).
 //
-// A wavefront takes 8 rays at a time, rows staged in LDS:
-//   weights -> +1e-5 -> sum -> pdf -> cdf        (serial along the ray: one ray per lane)
+// A wavefront takes 64 rays at a time, rows staged in LDS:
+//   weights -> +1e-5 -> sum -> pdf -> cdf        (serial along the ray: one ray per lane, all 64 lanes busy)
 //   u -> searchsorted(right) by binary search over the LDS cdf, one sample per lane per step
 //   samples -> LDS -> merge with the coarse depths by rank -> coalesced store
 //
@@ -85,7 +85,13 @@ __device__ __forceinline__ int count_sorted(const float* a, int n, float v) {
 }
 
 constexpr int PDF_WAVES = 1;      // wavefronts per workgroup
-constexpr int PDF_GROUP = 8;      // rays a wavefront takes through the serial phases together
+#ifndef NERF_PDF_GROUP
+#define NERF_PDF_GROUP 16
+#endif
+// Rays a wavefront takes through the serial phases together, one per lane.  More rays per group use more lanes there,
+// but their LDS rows (252 B per ray) cost occupancy, and the ray-by-ray phases are latency-bound: measured 0.40 ms
+// (16), 0.53 ms (32), 0.86 ms (64) for 640 000 rays.
+constexpr int PDF_GROUP = NERF_PDF_GROUP;
 
 // ATen's sum of one row w[0..n) (unit stride): the vectorised path for n >= 8 is eight strided
 // row sums combined after the scalar tail, lanes in order (SumKernel.cpp).
@@ -99,18 +105,161 @@ __device__ float row_sum_full(const float* w, int n) {
     return acc;
 }
 
-// A wavefront owns PDF_GROUP consecutive rays.  The parts of the algorithm that are serial along a ray
-// (the ATen-ordered sum and the float64 running sum of the cdf) run with ONE RAY PER LANE on rows staged in
-// LDS with an odd row stride (conflict-free); the parts that are parallel along a ray (searchsorted,
-// interpolation, merge) then run ray by ray with one sample per lane.
+// The serial phases for the wave's n_live rays: rows of [0, cdf 1..nw] in LDS (row stride sc floats).
+__device__ __forceinline__ void build_cdf_rows(const SamplePdfArgs& a, float* cdf_g, int sc, long long r0, int n_live, int lane) {
+    const int nw = a.nb - 1;
+    // ---- stage the weight rows (coalesced, one row per trip), + 1e-5, at positions 1..nw of the row
+    for (int g = 0; g < n_live; ++g) {
+        const float* wr = a.weights + (size_t)(r0 + g) * a.w_stride;
+        for (int i = lane; i < nw; i += WAVE) cdf_g[g * sc + 1 + i] = fadd(wr[i], 1e-5f);
+    }
+    __syncthreads();
+    // ---- one ray per lane: total in ATen order, then pdf = w / total (IEEE) and its float64 running sum, each prefix
+    //      rounded to float32, written over the weights
+    if (lane < n_live) {
+        float* row = cdf_g + lane * sc;
+        const float total = row_sum_full(row + 1, nw);
+        double c = 0.0;
+        row[0] = 0.f;
+        for (int i = 1; i <= nw; ++i) {
+            c = __dadd_rn(c, (double)fdiv(row[i], total));
+            row[i] = (float)c;
+        }
+    }
+    __syncthreads();
+
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The shape render_rays uses (run_nerf.py:393-401: 64 coarse depths -> 63 mid-point bins, 128 variates shared by all
+// rays, merged with the coarse depths): everything is a compile-time size, the searches are branch-free with
+// immediate LDS offsets, the variates stay in registers, sums go through DPP.  Same arithmetic, operation by
+// operation, as the general kernel below.
+constexpr int FAST_NB = 63, FAST_NU = 128, FAST_NZ = 64, FAST_SC = 63;
+
+template <int CTRL>
+__device__ __forceinline__ float pdf_dpp(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {          // total in every lane
+    v += pdf_dpp<0x111>(0.f, v);      // row_shr 1, 2, 4, 8: lane 15 of each row holds the row's sum
+    v += pdf_dpp<0x112>(0.f, v);
+    v += pdf_dpp<0x114>(0.f, v);
+    v += pdf_dpp<0x118>(0.f, v);
+    auto at = [&](int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+    return (at(15) + at(31)) + (at(47) + at(63));
+}
+// number of entries of the sorted array a[0 .. 2^LOG - 1) that are <= v (LE) or < v
+template <int LOG, bool LE>
+__device__ __forceinline__ int count_fixed(const float* a, float v) {
+    int pos = 0;
+#pragma unroll
+    for (int step = 1 << (LOG - 1); step >= 1; step >>= 1) {
+        const float c = a[pos + step - 1];
+        pos += (LE ? (c <= v) : (c < v)) ? step : 0;
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(64) void sample_pdf_fast_kernel(SamplePdfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    float* cdf_g = smem;                                      // [PDF_GROUP][63]
+    float* bins_s = cdf_g + PDF_GROUP * FAST_SC;              // 64 (63 used)
+    float* zs_s = bins_s + 64;                                // 128
+    float* zc_s = zs_s + FAST_NU;                             // 64
+    const long long r0 = (long long)blockIdx.x * PDF_GROUP;
+    const int n_live = (int)(a.R - r0 < PDF_GROUP ? a.R - r0 : PDF_GROUP);
+    build_cdf_rows(a, cdf_g, FAST_SC, r0, n_live, lane);
+    const float u0 = a.u[lane], u1 = a.u[lane + 64];
+
+    for (int g = 0; g < n_live; ++g) {
+        const long long ray = r0 + g;
+        const float* cdf_s = cdf_g + g * FAST_SC;
+        const float zc = a.bins[(size_t)ray * a.bins_stride + lane];              // the coarse depths ARE the bin source
+        zc_s[lane] = zc;
+        __syncthreads();
+        const float zn = zc_s[lane < 63 ? lane + 1 : 63];
+        bins_s[lane] = fmul(0.5f, fadd(zn, zc));                                  // lane 63: unused
+        __syncthreads();
+
+        float sv[2];
+        int iv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float u = q ? u1 : u0;
+            const int ind = count_fixed<6, true>(cdf_s, u);                       // 63 entries
+            const int below = max(ind - 1, 0), above = min(ind, FAST_NB - 1);
+            const float cb = cdf_s[below], ca = cdf_s[above];
+            float denom = fsub(ca, cb);
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = fdiv(fsub(u, cb), denom);
+            const float bb = bins_s[below], ba = bins_s[above];
+            sv[q] = fadd(bb, fmul(t, fsub(ba, bb)));
+            iv[q] = ind;
+            zs_s[lane + 64 * q] = sv[q];
+            const size_t o = (size_t)ray * FAST_NU + lane + 64 * q;
+            if (a.z_samples) a.z_samples[o] = sv[q];
+            if (a.inds) a.inds[o] = ind;
+        }
+        __syncthreads();
+
+        if (a.z_std) {
+            const float mean = wave_sum_dpp(sv[0] + sv[1]) / (float)FAST_NU;
+            const float d0 = sv[0] - mean, d1 = sv[1] - mean;
+            const float var = wave_sum_dpp(d0 * d0 + d1 * d1) / (float)FAST_NU;
+            if (lane == 0) a.z_std[ray] = sqrtf(var);
+        }
+
+        // sort(cat([z_vals, z_samples])) by rank; ties: coarse depths first, then samples by index
+        float* out = a.z_sorted + (size_t)ray * (FAST_NZ + FAST_NU);
+        const float nx0 = zs_s[lane + 1], nx1 = zs_s[lane < 63 ? lane + 65 : 127];
+        const bool sorted = __all(sv[0] <= nx0 && sv[1] <= nx1);
+        if (sorted) {
+            // 128 sorted samples: all of them below zc, or the count among the first 127
+            out[lane + ((zs_s[FAST_NU - 1] < zc) ? FAST_NU : count_fixed<7, false>(zs_s, zc))] = zc;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float v = sv[q];
+                const int ind = iv[q];
+                // v lies between the mid-points around coarse depth number ind: ind or ind + 1 depths are <= v
+                int c = ind + ((ind < FAST_NZ && zc_s[min(ind, FAST_NZ - 1)] <= v) ? 1 : 0);
+                const bool ok = (c == 0 || zc_s[max(c - 1, 0)] <= v) && (c == FAST_NZ || zc_s[min(c, FAST_NZ - 1)] > v);
+                if (!ok) c = count_sorted<true>(zc_s, FAST_NZ, v);
+                out[lane + 64 * q + c] = v;
+            }
+        } else {
+            int r = lane;
+            for (int k = 0; k < FAST_NU; ++k) r += (zs_s[k] < zc) ? 1 : 0;
+            out[r] = zc;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float v = sv[q];
+                const int j = lane + 64 * q;
+                int rr = count_sorted<true>(zc_s, FAST_NZ, v);
+                for (int k = 0; k < FAST_NU; ++k) {
+                    const float o = zs_s[k];
+                    rr += (o < v || (o == v && k < j)) ? 1 : 0;
+                }
+                out[rr] = v;
+            }
+        }
+        __syncthreads();      // the per-ray buffers are reused by the next ray
+    }
+}
+
+// A wavefront owns PDF_GROUP = 64 consecutive rays.  The parts of the algorithm that are serial along a ray (the
+// ATen-ordered sum, the division by it and the float64 running sum of the cdf) run with ONE RAY PER LANE on rows staged
+// in LDS with an odd row stride (conflict-free); the cdf overwrites the weights in place.  The parts that are parallel
+// along a ray (searchsorted, interpolation, merge) then run ray by ray with one sample per lane.
 __global__ __launch_bounds__(PDF_WAVES * 64) void sample_pdf_kernel(SamplePdfArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nb = a.nb, nw = a.nb - 1, n_u = a.n_u, n_z = a.z_sorted ? a.n_z : 0;
-    const int sw = nw | 1, sc = nb | 1;                       // odd row strides
-    const int per_wave = PDF_GROUP * (sw + sc) + nb + 2 * n_u + n_z;
-    float* w_g = smem + (size_t)wv * per_wave;                // [PDF_GROUP][sw] weights + 1e-5
-    float* cdf_g = w_g + PDF_GROUP * sw;                      // [PDF_GROUP][sc]
+    const int nb = a.nb, n_u = a.n_u, n_z = a.z_sorted ? a.n_z : 0;
+    const int sc = nb | 1;                                    // odd row stride
+    const int per_wave = PDF_GROUP * sc + nb + 2 * n_u + n_z;
+    float* cdf_g = smem + (size_t)wv * per_wave;              // [PDF_GROUP][sc]: row = [0, cdf 1..nw]; first holds w + 1e-5
     float* bins_s = cdf_g + PDF_GROUP * sc;                   // the ray in flight: bins, samples, coarse depths
     float* zs_s = bins_s + nb;
     float* zc_s = zs_s + n_u;
@@ -119,41 +268,14 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void sample_pdf_kernel(SamplePdfArg
     // its bin (checked, with the binary search as fallback)
     const bool z_is_bins = a.bins_are_z && a.z_sorted && a.z_vals == a.bins && a.n_z == nb + 1;
     const long long r0 = ((long long)blockIdx.x * PDF_WAVES + wv) * PDF_GROUP;
-    const long long last = a.R - 1;
+    const int n_live = (int)(a.R - r0 < PDF_GROUP ? a.R - r0 : PDF_GROUP);
 
-    // ---- stage the weight rows (coalesced), + 1e-5
-    for (int g = 0; g < PDF_GROUP; ++g) {
-        const long long ray = r0 + g < a.R ? r0 + g : last;
-        const float* wr = a.weights + (size_t)ray * a.w_stride;
-        for (int i = lane; i < nw; i += WAVE) w_g[g * sw + i] = fadd(wr[i], 1e-5f);
-    }
-    __syncthreads();
-    // ---- one ray per lane: total in ATen order
-    float total = 1.0f;
-    if (lane < PDF_GROUP) total = row_sum_full(w_g + lane * sw, nw);
-    // pdf = w / total, one element per lane (IEEE division is long: keep it parallel along the ray)
-    for (int g = 0; g < PDF_GROUP; ++g) {
-        const float tg = __shfl(total, g, WAVE);
-        for (int i = lane; i < nw; i += WAVE) w_g[g * sw + i] = fdiv(w_g[g * sw + i], tg);
-    }
-    __syncthreads();
-    // ---- one ray per lane: float64 running sum, each prefix rounded to float32
-    if (lane < PDF_GROUP) {
-        const float* w = w_g + lane * sw;
-        float* cdf = cdf_g + lane * sc;
-        double c = 0.0;
-        cdf[0] = 0.f;
-        for (int i = 0; i < nw; ++i) {
-            c = __dadd_rn(c, (double)w[i]);
-            cdf[i + 1] = (float)c;
-        }
-    }
-    __syncthreads();
+    build_cdf_rows(a, cdf_g, sc, r0, n_live, lane);
 
     // ---- ray by ray: searchsorted, interpolation, z_std, merge
-    for (int g = 0; g < PDF_GROUP; ++g) {
-        const bool live = r0 + g < a.R;
-        const long long ray = live ? r0 + g : last;
+    for (int g = 0; g < n_live; ++g) {
+        const bool live = true;
+        const long long ray = r0 + g;
         const float* cdf_s = cdf_g + g * sc;
         const float* br = a.bins + (size_t)ray * a.bins_stride;
         for (int i = lane; i < nb; i += WAVE)
@@ -259,7 +381,14 @@ extern "C" int nerf_sample_pdf(const float* bins, int bins_stride, int bins_are_
     if (R == 0) return NERF_OK;
     SamplePdfArgs a{bins, bins_stride, bins_are_z, nb, weights, w_stride, u, n_u, u_per_ray, R,
                     z_vals, n_z, z_samples, inds, z_sorted, z_std};
-    const size_t per_wave = (size_t)PDF_GROUP * (((nb - 1) | 1) + (nb | 1)) + nb + 2 * (size_t)n_u + (z_sorted ? n_z : 0);
+    if (nb == FAST_NB && n_u == FAST_NU && !u_per_ray && bins_are_z && z_sorted && z_vals == bins && n_z == FAST_NZ) {
+        const size_t fast_shmem = ((size_t)PDF_GROUP * FAST_SC + 64 + FAST_NU + FAST_NZ) * sizeof(float);
+        hipLaunchKernelGGL(sample_pdf_fast_kernel, dim3((R + PDF_GROUP - 1) / PDF_GROUP), dim3(WAVE), fast_shmem,
+                           as_stream(stream), a);
+        NERF_LAUNCH_CHECK();
+        return NERF_OK;
+    }
+    const size_t per_wave = (size_t)PDF_GROUP * (nb | 1) + nb + 2 * (size_t)n_u + (z_sorted ? n_z : 0);
     const size_t shmem = per_wave * PDF_WAVES * sizeof(float);
     NERF_REQUIRE(shmem <= 64 * 1024, "nerf_sample_pdf: rows too long for the LDS staging (%zu bytes)", shmem);
     const int rays_per_block = PDF_WAVES * PDF_GROUP;

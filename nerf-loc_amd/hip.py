@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "lib", "libnerf_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 3      # 2: the training entry points take a precision argument; 3: nerf_mlp_backward_static
+ABI_VERSION = 4      # 2: training entry points take a precision; 3: nerf_mlp_backward_static; 4: nerf_mlp_forward_objects
 IN_FEATURES, IN_POINTS, IN_RAYS = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
 
@@ -33,12 +33,17 @@ _SIGNATURES = {
                                    ctypes.c_int, _c_float_p, ctypes.c_void_p]),
     "nerf_embed": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, _c_float_p,
                                   ctypes.c_void_p]),
+    "nerf_count_nonfinite": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong),
+                                            ctypes.c_void_p, ctypes.c_void_p]),
     "nerf_mlp_packed_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "nerf_mlp_pack": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_void_p]),
     "nerf_mlp_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         _c_float_p, ctypes.c_void_p]),
+    "nerf_mlp_forward_objects": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_void_p]),
     "nerf_raw2outputs": (ctypes.c_int, [_c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, _c_float_p,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
                                         _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
@@ -207,6 +212,23 @@ def embed(x, multires, include_input=True):
     return out.reshape(tuple(x.shape[:-1]) + (out.shape[-1],))
 
 
+def count_nonfinite(tensors):
+    """Number of NaN / Inf values in each of the given float32 device tensors: one launch per 16 tensors and no host
+    synchronisation (the result is an int32 device tensor)."""
+    ts = [_f32(t, "tensor %d" % i) for i, t in enumerate(tensors)]
+    dev = ts[0].device
+    out = torch.empty((len(ts),), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        for i in range(0, len(ts), 16):
+            part = ts[i:i + 16]
+            k = len(part)
+            ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in part])
+            numel = (ctypes.c_longlong * k)(*[t.numel() for t in part])
+            _check(lib().nerf_count_nonfinite(k, ptrs, numel, ctypes.c_void_p(out[i:].data_ptr()), _stream(out)),
+                   "nerf_count_nonfinite")
+    return out
+
+
 # --------------------------------------------------------------------------- network
 def mlp_pack(tensors, use_viewdirs, output_ch, precision):
     """tensors: list of device tensors in state_dict order (None allowed for the
@@ -242,6 +264,30 @@ def mlp_forward(packed, precision, use_viewdirs, output_ch, mode, in0, in1, R, S
         if ev is not None:
             e1.record(torch.cuda.current_stream(in0.device))
             ev.append((e0, e1, R * S))
+    return out
+
+
+def mlp_forward_objects(packed_list, precision, use_viewdirs, output_ch, mode, in0, in1, R, S, ray_cols=0):
+    """nerf_mlp_forward_objects: len(packed_list) networks, each evaluating its equal share of the R rays, one launch.
+    packed_list: packed streams (mlp_pack) on the device of in0."""
+    in0 = _f32(in0, "mlp input")
+    in1 = _f32(in1, "mlp second input", in0.device) if in1 is not None else None
+    n = len(packed_list)
+    table = torch.tensor([p.data_ptr() for p in packed_list], dtype=torch.int64).to(in0.device)
+    out = torch.empty((R * S, output_ch), dtype=torch.float32, device=in0.device)
+    ev = MLP_EVENTS
+    with torch.cuda.device(in0.device):
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(in0.device))
+        _check(lib().nerf_mlp_forward_objects(ctypes.cast(ctypes.c_void_p(table.data_ptr()), ctypes.POINTER(ctypes.c_void_p)),
+                                              n, precision, int(bool(use_viewdirs)), int(output_ch), mode, _ptr(in0),
+                                              _ptr(in1), int(R), int(S), int(ray_cols), _ptr(out), _stream(out)),
+               "nerf_mlp_forward_objects")
+        if ev is not None:
+            e1.record(torch.cuda.current_stream(in0.device))
+            ev.append((e0, e1, R * S))
+    out._nerf_keepalive = (table, list(packed_list))      # the launch reads them asynchronously
     return out
 
 

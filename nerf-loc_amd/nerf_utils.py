@@ -94,11 +94,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                          perturb=perturb, N_importance=0, network_fine=None, white_bkgd=white_bkgd,
                          raw_noise_std=raw_noise_std, verbose=verbose, pytest=pytest, _with_depth=True,
                          _render_rgb=nerf_render_rgb, _render_depth=nerf_render_depth)
-    for k in ret:
-        if k in ['disp_map'] or ret[k] is None:
-            continue
-        if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
-            print(f"! [Numerical Error] {k} contains nan or inf.")
+    _r.warn_nonfinite(ret, skip=('disp_map',))       # nerf_utils.py:336-340: every key but disp_map, on every render
     return ret
 
 
@@ -165,6 +161,28 @@ def render_path_device(render_poses, hwf, K, render_kwargs, render_factor=0):
     return shp(ret['rgb_map']), shp(ret.get('disp_map')), shp(ret.get('raw')), shp(ret.get('depth_map'))
 
 
+def render_path_device_objects(render_poses, hwf, K, render_kwargs_list, render_factor=0):
+    """render_path_device for SEVERAL objects at once: object o is rendered with render_kwargs_list[o] (its own
+    network_fn, everything else taken from the first entry) from render_poses[o] (all objects: the same number of
+    poses, one image size).  K: one 3x3 matrix for all, or one per object.  All objects' rays form one batch and the
+    networks run as one launch (nerf_mlp_forward_objects); the reference renders scan after scan, pose after pose
+    (model_3detr.py:619-724).  Returns (rgbs [O,P,H,W,3], disps [O,P,H,W], raws [O,P,H,W,S,C] or None, depths [O,P,H,W])."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W = H // render_factor, W // render_factor
+    kw = dict(render_kwargs_list[0])
+    near, far = kw.pop('near', 0.), kw.pop('far', 1.)
+    use_viewdirs, ndc = kw.pop('use_viewdirs', False), kw.pop('ndc', False)
+    O, P = len(render_kwargs_list), len(render_poses[0])
+    Ks = K if (isinstance(K, (list, tuple)) and len(K) == O and np.ndim(K[0]) == 2) else [K] * O
+    rays = torch.cat([_r._build_rays(H, W, Ks[o], None, c2w[:3, :4], ndc, near, far, use_viewdirs, None)[0]
+                      for o in range(O) for c2w in render_poses[o]], 0)
+    kw['network_fn'] = [k['network_fn'] for k in render_kwargs_list]
+    ret = batchify_rays(rays, rays.shape[0], **kw)
+    shp = lambda t: None if t is None else t.reshape([O, P, H, W] + list(t.shape[1:]))
+    return shp(ret['rgb_map']), shp(ret.get('disp_map')), shp(ret.get('raw')), shp(ret.get('depth_map'))
+
+
 _DEPTH_TYPES = ('rendered_depth', 'nerf_rendered_depth', 'nerf_rendered_rgb_rendered_depth', 'rendered_rgb_rendered_depth')
 
 
@@ -214,5 +232,35 @@ def detector_inputs(poses, render_kwargs, input_type='nerf', focal_length=None):
     out['raws'] = _assemble(input_type, rgbs, depths, raws, depths)
     if focal_length is not None:
         c_rgbs, c_depths, c_raws = one(focal / focal_length, 'coarse_')
+        out['coarse_raws'] = _assemble(input_type, c_rgbs, c_depths, c_raws, depths)
+    return out
+
+
+def detector_inputs_batch(poses, render_kwargs_list, input_type='nerf', focal_length=None):
+    """detector_inputs for a batch of scans, each with its own network (what one Model3DETR.forward call renders when
+    none of its scans is cached, model_3detr.py:619-724): poses [B, P, 3, 5].  One network launch per field of view
+    for the whole batch.  Returns the same keys as detector_inputs with a leading batch dimension."""
+    B = len(render_kwargs_list)
+    poses = poses.reshape(B, -1, 3, 5)
+    hwf = poses[:, 0, :3, -1].cpu()
+    H, W = int(hwf[0, 0]), int(hwf[0, 1])
+    if not (bool((hwf[:, 0] == H).all()) and bool((hwf[:, 1] == W).all())):
+        raise ValueError("the scans of a batch must share the image size")
+    focals = [float(f) for f in hwf[:, 2]]
+    render_poses = [poses[b, :, :3, :4] for b in range(B)]
+    out = {}
+
+    def one(scale, tag):
+        Ks = [np.array([[f * scale, 0, 0.5 * W], [0, f * scale, 0.5 * H], [0, 0, 1]]) for f in focals]
+        rgbs, disps, raws, depths = render_path_device_objects(render_poses, [H, W, focals[0]], Ks, render_kwargs_list)
+        if input_type in _DEPTH_TYPES:
+            depths, disps = torch.nan_to_num(depths, nan=1.), torch.nan_to_num(disps, nan=1.)
+        out[tag + 'rgbs'], out[tag + 'disps'], out[tag + 'depths'] = rgbs, disps, depths
+        return rgbs, depths, raws
+
+    rgbs, depths, raws = one(1.0, '')
+    out['raws'] = _assemble(input_type, rgbs, depths, raws, depths)
+    if focal_length is not None:
+        c_rgbs, c_depths, c_raws = one(1.0 / focal_length, 'coarse_')
         out['coarse_raws'] = _assemble(input_type, c_rgbs, c_depths, c_raws, depths)
     return out

@@ -46,6 +46,32 @@ def _fusable(fn, embed_fn, embeddirs_fn, has_viewdirs):
     return not has_viewdirs
 
 
+def _query_objects(nets, query_fn, rays, z, has_vd):
+    """Several networks, each evaluating its equal share of the ray batch: one launch when the shares line up with
+    the kernel's tiles (nerf_mlp_forward_objects), else one launch per network on its slice."""
+    n, N_rays, S, cols = len(nets), rays.shape[0], z.shape[1], rays.shape[1]
+    first = nets[0]
+    if N_rays % n:
+        raise ValueError("%d rays do not split evenly over %d networks" % (N_rays, n))
+    for net in nets:
+        if not query_fn.fusable(net, has_vd):
+            raise NotImplementedError("a batch of networks needs this package's NeRF modules and embedders")
+        if (net.use_viewdirs, net.out_channels, net.precision_code()) != (first.use_viewdirs, first.out_channels,
+                                                                          first.precision_code()):
+            raise ValueError("the networks of a batch must share architecture and precision")
+    prec = first.precision_code()
+    per = N_rays // n
+    tile = 256 if prec == hip.PREC_BF16 else 128
+    if N_rays and (per * S) % tile == 0:
+        out = hip.mlp_forward_objects([net.packed_weights(prec) for net in nets], prec, first.use_viewdirs,
+                                      first.out_channels, hip.IN_RAYS, rays, z, N_rays, S, cols)
+    else:
+        out = torch.cat([hip.mlp_forward(net.packed_weights(prec), prec, net.use_viewdirs, net.out_channels, hip.IN_RAYS,
+                                         rays[i * per:(i + 1) * per], z[i * per:(i + 1) * per], per, S, cols)
+                         for i, net in enumerate(nets)], 0)
+    return out.reshape(N_rays, S, first.out_channels)
+
+
 def _needs_grad(fn):
     return torch.is_grad_enabled() and isinstance(fn, torch.nn.Module) and any(p.requires_grad for p in fn.parameters())
 
@@ -157,6 +183,10 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                                           N_importance, network_fine, white_bkgd, raw_noise_std, pytest, _with_depth)
 
     def query(net, z):
+        if isinstance(net, (list, tuple)):       # one network per object: equal consecutive shares of the ray batch
+            if not fused:
+                raise NotImplementedError("a batch of networks needs the NetworkQuery that create_nerf builds")
+            return _query_objects(net, network_query_fn, rays, z, has_vd)
         if fused and network_query_fn.fusable(net, has_vd):
             prec = net.precision_code()
             out = hip.mlp_forward(net.packed_weights(prec), prec, net.use_viewdirs, net.out_channels, hip.IN_RAYS,
@@ -194,10 +224,19 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         ret['acc0'] = acc_map_0
         ret['z_std'] = z_std
     if DEBUG:
-        for k in ret:
-            if ret[k] is not None and (torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any()):
-                print(f"! [Numerical Error] {k} contains nan or inf.")
+        warn_nonfinite(ret)
     return ret
+
+
+def warn_nonfinite(ret, skip=()):
+    """The reference's NaN / Inf warning (run_nerf.py:420-422), from one census launch and one read-back."""
+    keys = [k for k in ret if ret[k] is not None and k not in skip and ret[k].dtype == torch.float32 and ret[k].numel()]
+    if not keys:
+        return
+    counts = hip.count_nonfinite([ret[k] for k in keys]).tolist()
+    for k, c in zip(keys, counts):
+        if c:
+            print(f"! [Numerical Error] {k} contains nan or inf.")
 
 
 # ---------------------------------------------------------------------------- run_nerf.py:54-134

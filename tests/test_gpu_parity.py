@@ -623,6 +623,63 @@ def test_invalid_arguments_raise(dev):
         hip.z_vals(rays.double(), 8)
 
 
+# ------------------------------------------------------------------ several networks in one launch
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_object_batch_equals_per_object_renders(dev, precision):
+    """Three objects, each with its own network, rendered as one batch (nerf_mlp_forward_objects: one network launch)
+    against three separate renders: bit for bit, in both precisions; shares that do not fill the kernel's tiles take
+    the per-object path and give the same."""
+    import types
+    from nerf_loc_amd import nerf_utils
+    args = types.SimpleNamespace(nerf_render_rgb=True, nerf_render_depth=True)
+    kws = []
+    for o in range(3):
+        _, kw, _ = nerf_utils.create_nerf_model(args, ckpt_path=None, device=dev, near=0.1, far=9.0)
+        kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(70 + o, "B").items()})
+        kw["network_fn"].requires_grad_(False)
+        kw["network_fn"].precision = precision
+        kws.append(kw)
+    for H, W in ((16, 12), (10, 9)):         # 2 poses x 192 rays x 64 samples = 96 tiles of 256; 2 x 90 x 64: not a multiple
+        K = np.array([[14.0, 0, 0.5 * W], [0, 14.0, 0.5 * H], [0, 0, 1]])
+        poses = [[T(synth.pose_spherical(40.0 * o + 25.0 * i, -25.0, 1.6)[:3, :4].astype(F32), dev) for i in range(2)]
+                 for o in range(3)]
+        rgbs, disps, raws, depths = nerf_utils.render_path_device_objects(poses, [H, W, 14.0], K, kws)
+        assert tuple(raws.shape) == (3, 2, H, W, 64, 4) and tuple(rgbs.shape) == (3, 2, H, W, 3)
+        for o in range(3):
+            r1, d1, w1, z1 = nerf_utils.render_path_device(poses[o], [H, W, 14.0], K, kws[o])
+            assert torch.equal(raws[o], w1) and torch.equal(rgbs[o], r1) and torch.equal(depths[o], z1)
+            assert torch.equal(torch.nan_to_num(disps[o]), torch.nan_to_num(d1))
+        assert float((raws[0] - raws[1]).abs().max()) > 1e-3       # different networks did render different things
+    # the detector's input assembly for the batch of scans
+    H, W, focal = 16, 12, 14.0
+    pb = np.zeros((3, 2, 3, 5), F32)
+    for o in range(3):
+        for i in range(2):
+            pb[o, i, :, :4] = synth.pose_spherical(40.0 * o + 25.0 * i, -25.0, 1.6)[:3, :4]
+            pb[o, i, :, 4] = (H, W, focal)
+    got = nerf_utils.detector_inputs_batch(T(pb, dev), kws, input_type="nerf_rendered_rgb_rendered_depth", focal_length=1.2)
+    for o in range(3):
+        one = nerf_utils.detector_inputs(T(pb[o], dev), kws[o], input_type="nerf_rendered_rgb_rendered_depth", focal_length=1.2)
+        for k in ("raws", "coarse_raws", "rgbs", "depths", "coarse_depths"):
+            assert torch.equal(got[k][o], one[k]), (o, k)
+
+
+def test_nonfinite_census(dev):
+    from nerf_loc_amd import hip, render
+    a = torch.zeros(100003, device=dev)
+    b = torch.ones((7, 5), device=dev)
+    c = torch.zeros(0, device=dev)
+    a[5], a[100002], a[77] = float("nan"), float("inf"), -float("inf")
+    assert hip.count_nonfinite([a, b, c]).tolist() == [3, 0, 0]
+    many = [torch.full((3,), float("nan") if i % 3 == 0 else 1.0, device=dev) for i in range(20)]
+    assert hip.count_nonfinite(many).tolist() == [3 if i % 3 == 0 else 0 for i in range(20)]
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        render.warn_nonfinite({"rgb_map": a, "disp_map": a, "acc_map": b, "none": None}, skip=("disp_map",))
+    assert buf.getvalue().count("Numerical Error") == 1 and "rgb_map" in buf.getvalue()
+
+
 # ------------------------------------------------------------------ full size, size-independent properties
 def test_full_size_view_properties(dev):
     """The 800 x 800, 64 + 128 workload of the benchmark (640 000 rays) in float32 mode: what must hold at any size
