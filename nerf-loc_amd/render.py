@@ -302,8 +302,8 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=False, near=0., fa
 def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
     """Renders one image per pose and returns (rgbs, disps) as numpy arrays
     (run_nerf.py:137-181; run_multi_nerf.py guards the 'retraw' lookups).  With
-    savedir the frames are written as .npy (raw volume, if requested) and, when
-    imageio is installed, .png."""
+    savedir each frame is written as '{:06d}.png' and, with retraw, its raw volume
+    as '{:06d}.npy'."""
     H, W, focal = hwf
     if render_factor != 0:
         H = H // render_factor
@@ -320,11 +320,15 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
 
 
 def _save_frame(savedir, i, rgb, raw):
+    """The frame dump of run_nerf.py:170-175: '{:06d}.png' (8-bit) and, with retraw, '{:06d}.npy' of the raw volume.
+    imageio is used when installed, else the package's own PNG writer."""
+    path = os.path.join(savedir, '{:06d}.png'.format(i))
     try:
         import imageio
-        imageio.imwrite(os.path.join(savedir, '{:06d}.png'.format(i)), to8b(rgb))
+        imageio.imwrite(path, to8b(rgb))
     except ImportError:
-        np.save(os.path.join(savedir, '{:06d}_rgb8.npy'.format(i)), to8b(rgb))
+        from .poses import write_png
+        write_png(path, to8b(rgb))
     if raw is not None:
         np.save(os.path.join(savedir, '{:06d}.npy'.format(i)), raw.cpu().numpy())
 

@@ -26,6 +26,7 @@ Fixtures (all float32 unless noted):
   g10_checkpoint.npz  one reference training step (NeRF + torch.optim.Adam) and the checkpoint dict of
                       run_nerf.py:803-811 written and re-read: key names, optimizer-state layout, and the small
                       tensors after the step (the full checkpoint is 14 MB and is not stored)
+  g11_poses.npz       load_llff.py pose pipeline (recentre, spiral, spherify) and load_blender.pose_spherical
 """
 import os
 import sys
@@ -414,7 +415,49 @@ def g10():
     save("g10_checkpoint.npz", **out)
 
 
+# ---------------------------------------------------------------- g11
+def g11():
+    """Pose utilities of load_llff.py on a synthetic poses_bounds array: load_llff_data itself with its image reader
+    replaced (no image files exist here), spiral / spherify variants, and pose_spherical of load_blender.py."""
+    import load_llff
+    import load_blender
+    rs = np.random.RandomState(11)
+    N = 14
+    arr = np.zeros((N, 17))
+    for i in range(N):
+        c2w = synth.pose_spherical(rs.uniform(-40, 40), rs.uniform(-35, -5), rs.uniform(3.5, 4.5))[:3, :4].astype(np.float64)
+        c2w[:, 3] += rs.normal(size=3) * 0.05
+        # LLFF stores [down, right, back] columns and a hwf column; here simply a consistent synthetic set
+        p = np.concatenate([c2w[:, 1:2], c2w[:, 0:1], -c2w[:, 2:3], c2w[:, 3:4], np.array([[1440.], [1920.], [1571.66]])], 1)
+        arr[i, :15] = p.reshape(-1)
+        arr[i, 15:] = (rs.uniform(1.0, 1.5), rs.uniform(8.0, 12.0))
+    out = dict(poses_bounds=arr)
+    H, W, pose_factor = 240, 180, 8
+
+    def fake_load(basedir, factor=None, width=None, height=None, load_imgs=True, pose_factor=None):
+        poses = arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0]).copy()
+        bds = arr[:, -2:].transpose([1, 0]).copy()
+        poses[:2, 4, :] = np.array([H, W]).reshape([2, 1])
+        poses[2, 4, :] = poses[2, 4, :] * 1. / pose_factor
+        out["parsed_poses"], out["parsed_bds"] = poses.copy(), bds.copy()
+        return poses, bds, np.zeros((H, W, 3, N))
+    orig = load_llff._load_data
+    load_llff._load_data = fake_load
+    try:
+        for tag, kw in (("spiral", {}), ("sphere", dict(spherify=True)),      # path_zflat: the reference's N_views/2 is a float that numpy's linspace refuses
+
+                        ("norecenter", dict(recenter=False, bd_factor=None))):
+            images, poses, bds, render_poses, i_test = load_llff.load_llff_data("none", factor=8, pose_factor=pose_factor, **kw)
+            out[tag + "_poses"], out[tag + "_bds"], out[tag + "_render_poses"] = poses, bds, render_poses
+            out[tag + "_i_test"] = np.array(i_test)
+    finally:
+        load_llff._load_data = orig
+    out["pose_spherical"] = np.stack([n(load_blender.pose_spherical(a, -30.0, 4.0)) for a in np.linspace(-180, 180, 8 + 1)[:-1]])
+    out["hw_pf"] = np.array([H, W, pose_factor])
+    save("g11_poses.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for g in which:
         globals()[g]()

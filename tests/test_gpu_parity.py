@@ -5,6 +5,8 @@ Tolerances: deterministic sample_pdf indices and
 samples bit-exact for identical inputs; float32 maps within 1e-4 absolute; the
 bf16-MFMA mode within 1e-2 absolute and 0.1 dB PSNR.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -485,6 +487,27 @@ def test_render_image_both_flavours(dev, golden):
                                                                        kw_test)
     assert d_rgbs.is_cuda and tuple(d_raws.shape) == (2, H, W, 64, 4)
     assert np.array_equal(N(d_rgbs), rgbs) and np.array_equal(N(d_depths), depths) and np.array_equal(N(d_raws), raws)
+
+
+def test_render_path_writes_frames(dev, golden, tmp_path):
+    """render_path(savedir=...) leaves '{:06d}.png' (the 8-bit image of the returned rgb) and, with retraw,
+    '{:06d}.npy' of the raw volume per pose (run_nerf.py:170-175)."""
+    from nerf_loc_amd import render, poses as P
+    g = golden("g9_render")
+    H, W = [int(v) for v in g["lego_hw"]]
+    nc = load_net(synth.make_state_dict(90, "B"), dev)
+    kw = dict(network_query_fn=_query(dev), perturb=0.0, N_importance=0, network_fine=None, N_samples=64,
+              network_fn=nc, use_viewdirs=True, white_bkgd=True, raw_noise_std=0.0, ndc=False, lindisp=False,
+              near=2.0, far=6.0, retraw=True)
+    c2w = T(g["lego_c2w"], dev)
+    rgbs, disps = render.render_path(torch.stack([c2w, c2w]), [H, W, float(g["lego_K"][0, 0])], g["lego_K"], 1024, kw,
+                                     savedir=str(tmp_path))
+    assert rgbs.shape == (2, H, W, 3)
+    assert sorted(os.listdir(tmp_path)) == ["000000.npy", "000000.png", "000001.npy", "000001.png"]
+    for i in range(2):
+        img = P.read_png(str(tmp_path / ("%06d.png" % i)))
+        assert np.array_equal(img, (255 * np.clip(rgbs[i], 0, 1)).astype(np.uint8))
+        assert np.load(str(tmp_path / ("%06d.npy" % i))).shape == (H, W, 64, 4)
 
 
 # ------------------------------------------------------------------ bf16 mode end to end
