@@ -6,9 +6,9 @@ set -u
 out=$1; prec=$2
 mkdir -p "$out"
 export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 3 --warmup 1 --precision "$prec" --no-cpu-baseline > "$out/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$out/trace.log"; exit 1; }
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 3 --warmup 1 --precision "$prec" --no-cpu-baseline --no-extras > "$out/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$out/trace.log"; exit 1; }
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -- python3 bench.py --steps 1 --warmup 1 --precision "$prec" --no-cpu-baseline > "$out/pmc_$c.log" 2>&1 || { echo "$c pass failed"; tail -5 "$out/pmc_$c.log"; exit 1; }
+  timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -- python3 bench.py --steps 1 --warmup 1 --precision "$prec" --no-cpu-baseline --no-extras > "$out/pmc_$c.log" 2>&1 || { echo "$c pass failed"; tail -5 "$out/pmc_$c.log"; exit 1; }
 done
 python3 - "$out" "$prec" <<'PY'
 import collections, csv, glob, json, sys
@@ -22,7 +22,7 @@ for r in rows:
     per[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 tot = sum(sum(v) for v in per.values())
 with open(out + "/kernel_stats.txt", "w") as fo:
-    fo.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --precision %s --no-cpu-baseline\n" % prec)
+    fo.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --precision %s --no-cpu-baseline --no-extras\n" % prec)
     fo.write("%-64s %6s %12s %10s %10s %10s %7s\n" % ("kernel", "calls", "total_ms", "avg_ms", "min_ms", "max_ms", "share"))
     for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
         fo.write("%-64s %6d %12.3f %10.4f %10.4f %10.4f %6.2f%%\n" % (k[:64], len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot))
