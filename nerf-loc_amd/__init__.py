@@ -9,7 +9,7 @@ import importlib
 
 __version__ = "0.1.0"
 
-_LAZY = ("synth", "hip", "helpers", "render", "nerf_utils", "dist", "train", "raybank")
+_LAZY = ("synth", "hip", "helpers", "render", "nerf_utils", "dist", "train", "raybank", "poses", "objectbank")
 
 
 def __getattr__(name):

@@ -85,3 +85,30 @@ def test_png_rejects_other_types(tmp_path):
         P.write_png(str(tmp_path / "a.png"), np.zeros((2, 2, 3), np.float32))
     with pytest.raises(ValueError):
         P.write_png(str(tmp_path / "a.png"), np.zeros((2, 2, 2), np.uint8))
+
+
+def test_objectbank_reader_orders_and_checks_tensors(tmp_path):
+    """Host half of the object bank: a checkpoint becomes one flat buffer in state_dict order; foreign layouts raise."""
+    import torch
+    from nerf_loc_amd import synth
+    from nerf_loc_amd.helpers import NeRF
+    from nerf_loc_amd.objectbank import read_flat, state_dict_layout
+    net = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
+    layout, total = state_dict_layout(net)
+    assert total == 595844 and [n for n, _, _, _ in layout] == list(net.state_dict().keys())
+    sd = synth.make_state_dict(5, "A")
+    path = str(tmp_path / "a.tar")
+    torch.save({'global_step': 77, 'network_fn_state_dict': {k: torch.from_numpy(v) for k, v in sd.items()}}, path)
+    flat, step = read_flat(path, layout, total)
+    assert step == 77 and flat.shape == (total,)
+    for name, shape, off, n in layout:
+        assert np.array_equal(flat[off:off + n].numpy().reshape(shape), sd[name]), name
+    sd2 = dict(sd)
+    sd2["alpha_linear.weight"] = np.zeros((2, 256), np.float32)
+    torch.save({'global_step': 0, 'network_fn_state_dict': {k: torch.from_numpy(v) for k, v in sd2.items()}}, path)
+    with pytest.raises(ValueError):
+        read_flat(path, layout, total)
+    del sd2["alpha_linear.weight"]
+    torch.save({'global_step': 0, 'network_fn_state_dict': {k: torch.from_numpy(v) for k, v in sd2.items()}}, path)
+    with pytest.raises(ValueError):
+        read_flat(path, layout, total)
