@@ -58,6 +58,7 @@ __device__ float row_sum_aten(const float* x, int n, int stride) {
 }
 
 struct SamplePdfArgs {
+    int skip_if_grid;      // fast kernel: leave at once when the variates are the ascending grid (the row kernel ran)
     const float* bins; int bins_stride; int bins_are_z; int nb;
     const float* weights; int w_stride;
     const float* u; int n_u; int u_per_ray; int R;
@@ -162,9 +163,12 @@ __device__ __forceinline__ int count_fixed(const float* a, float v) {
     return pos;
 }
 
+__device__ __forceinline__ bool variates_on_grid(const float* u, int lane);
+
 __global__ __launch_bounds__(64) void sample_pdf_fast_kernel(SamplePdfArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
+    if (a.skip_if_grid && variates_on_grid(a.u, lane)) return;     // sample_pdf_row_kernel took this launch's rays
     float* cdf_g = smem;                                      // [PDF_GROUP][63]
     float* bins_s = cdf_g + PDF_GROUP * FAST_SC;              // 64 (63 used)
     float* zs_s = bins_s + 64;                                // 128
@@ -246,6 +250,367 @@ __global__ __launch_bounds__(64) void sample_pdf_fast_kernel(SamplePdfArgs a) {
             }
         }
         __syncthreads();      // the per-ray buffers are reused by the next ray
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same shape when the shared variates ascend along the regular grid k / 127 (what render_rays passes when it does
+// not perturb: torch.linspace(0, 1, 128), run_nerf_helpers.py:210-212): ONE 16-LANE ROW PER RAY, four rays per
+// wavefront.  A lane owns 4 consecutive weights / cdf entries / coarse depths and 8 consecutive samples, so all
+// per-ray bookkeeping (sums, scans, checks) is a handful of DPP row operations shared by four rays, and nothing is
+// searched:
+//   searchsorted(cdf, u_k, right) = #{m : cdf_m <= u_k} = #{m : cnt_m <= k},   cnt_m = #{k : u_k < cdf_m}
+// because u ascends; cnt_m comes from the grid (candidate trunc(127 cdf_m), settled by comparing cdf_m with the three
+// variates around it: the float comparisons a search would make), a 129-bin histogram of the counts in LDS and a
+// prefix sum give the index of every sample.  Merge: a sample of bin i lies between the mid-points around coarse
+// depth i, so i or i + 1 depths are <= it (checked against its neighbours); depth m is preceded by the cnt_{m-1}
+// samples of lower bins and by the samples of its own bin that lie below it (second histogram).
+// The float64 running sum of the cdf is done as a parallel scan: every pdf value is a float32 of at least 2^-28 and
+// the sum stays below 2, so all partial sums are multiples of 2^-52 below 2 - exactly representable, in any order.
+// Rows for which that cannot be shown (checked), or whose samples / counts do not ascend, take slow exact paths.
+#ifndef NERF_ROW_WAVES
+#define NERF_ROW_WAVES 5
+#endif
+// LDS of one row (floats): the weights + 1e-5 as staged for the row sum; the nine partial sums; cdf and bin mid-points
+// INTERLEAVED (entry i: cdf_i at 2 i, mid-point i at 2 i + 1) with sentinel entries -1 and 63 that are copies of
+// entries 0 and 62, so that the reference's clamped lookups [max(i - 1, 0)], [min(i, 62)] of both arrays are the four
+// consecutive floats at entry i - 1: one LDS instruction per sample; the coarse depths; the two marker arrays.
+constexpr int ROW_FS = 0, ROW_PARTS = 64, ROW_CB = 84, ROW_ZC = 216, ROW_MARK = 284, ROW_H2 = 284 + 132, ROW_LDS = 284 + 132 + 68;
+constexpr int MARK_DUMMY = 129, H2_DUMMY = 64;      // where a lane that has nothing to mark writes
+
+template <int CTRL>
+__device__ __forceinline__ int row_dpp_i(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float row_dpp_f(float old, float src) {
+    return __builtin_bit_cast(float, row_dpp_i<CTRL>(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src)));
+}
+template <int CTRL>
+__device__ __forceinline__ double row_dpp_d(double old, double src) {
+    const long long o = __builtin_bit_cast(long long, old), v = __builtin_bit_cast(long long, src);
+    const unsigned lo = (unsigned)row_dpp_i<CTRL>((int)(unsigned)o, (int)(unsigned)v);
+    const unsigned hi = (unsigned)row_dpp_i<CTRL>((int)(unsigned)(o >> 32), (int)(unsigned)(v >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+constexpr int ROW_SHR = 0x110, ROW_SHL = 0x100;
+
+// torch.linspace(0, 1, 128) as ATen's CPU kernel evaluates it: step = 1 / 127 in float; first half start + step k,
+// second half end - step (127 - k), each with one rounding
+__device__ __forceinline__ float grid_variate(int k) {
+    constexpr float step = 1.0f / 127.0f;
+    return k < 64 ? fmul(step, (float)k) : __builtin_fmaf(-step, (float)(127 - k), 1.0f);
+}
+// are the 128 shared variates exactly that grid?  (lane: variates 2 lane, 2 lane + 1)
+__device__ __forceinline__ bool variates_on_grid(const float* u, int lane) {
+    return __all(u[2 * lane] == grid_variate(2 * lane) && u[2 * lane + 1] == grid_variate(2 * lane + 1));
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NERF_ROW_WAVES))) void sample_pdf_row_kernel(SamplePdfArgs a, int n_quads) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * ROW_LDS];
+    const int lane = threadIdx.x, j = lane & 15, row = lane >> 4, row0 = lane & 48;
+    if (!variates_on_grid(a.u, lane)) return;                  // the bisection kernel, launched next, does the work
+    float* base = smem + row * ROW_LDS;
+    float* fs_s = base + ROW_FS;
+    float* parts_s = base + ROW_PARTS;
+    float* cb_s = base + ROW_CB;
+    float* zc_s = base + ROW_ZC;
+    int* mark = reinterpret_cast<int*>(base + ROW_MARK);        // slot c: 1 + the last cdf entry with count c
+    int* h2 = reinterpret_cast<int*>(base + ROW_H2);            // slot i: 1 + the last sample of bin i below depth i
+    float* out_s = base + ROW_MARK;                             // the merged row takes the markers' place once they are read
+    float* zs_s = base + ROW_MARK;                              // so do the samples in the slow merge
+    if (j == 0) cb_s[-2] = 0.f;                                 // sentinel entry -1: cdf[0] is 0 (its mid-point follows per ray)
+    float u[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) u[t] = grid_variate(8 * j + t);
+
+    // the global reads of a quad are issued one quad ahead
+    float zq[4], wq[4];
+    auto request = [&](int quad) {
+        const long long ru = (long long)quad * 4 + row;
+        const size_t r = (size_t)(ru < a.R ? ru : a.R - 1);
+        const float* zr = a.bins + r * a.bins_stride;
+        const float* wr = a.weights + r * a.w_stride;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = 4 * j + t;
+            zq[t] = zr[m];
+            wq[t] = wr[min(max(m - 1, 0), FAST_NB - 2)];
+        }
+    };
+    request(blockIdx.x < n_quads ? blockIdx.x : 0);
+    for (int quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+        const long long ray_u = (long long)quad * 4 + row;
+        const bool ray_ok = ray_u < a.R;
+        const size_t ray = ray_ok ? (size_t)ray_u : (size_t)(a.R - 1);      // idle rows redo the last ray and store nothing
+        // ---- coarse depths 4 j .. 4 j + 3, weights with the same numbers (weight m - 1 sits at cdf entry m)
+        float z[5], f[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = 4 * j + t;
+            z[t] = zq[t];
+            f[t] = (m >= 1 && m <= FAST_NB - 1) ? fadd(wq[t], 1e-5f) : 0.f;
+        }
+        request(quad + (int)gridDim.x < n_quads ? quad + (int)gridDim.x : quad);
+        __syncthreads();                                        // the previous quad's readers are done
+        *reinterpret_cast<float4*>(fs_s + 4 * j) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(zc_s + 4 * j) = make_float4(z[0], z[1], z[2], z[3]);
+        {
+            float4* mz = reinterpret_cast<float4*>(base + ROW_MARK);             // 200 floats of markers: 50 quads
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            mz[j] = zero; mz[16 + j] = zero; mz[32 + j] = zero;
+            if (j < 2) mz[48 + j] = zero;
+        }
+        z[4] = row_dpp_f<ROW_SHL + 1>(z[3], z[0]);              // the next lane's first depth (lane 15: its own last)
+        __syncthreads();
+
+        // ---- total of the 62 weights in ATen's order (row_sum_full for n = 62): eight strided partial sums and the
+        //      tail 56..61, each a chain of adds, combined tail first, then the partial sums in order
+        float part;
+        {
+            const int l = j < 8 ? j : 0;
+            // weight i sits at fs_s[i + 1]
+            const float x0 = fs_s[1 + (j == 8 ? 56 : l)], x1 = fs_s[1 + (j == 8 ? 57 : 32 + l)], x2 = fs_s[1 + (j == 8 ? 58 : 40 + l)],
+                        x3 = fs_s[1 + (j == 8 ? 59 : 48 + l)], x4 = fs_s[1 + (j == 8 ? 60 : 8 + l)], x5 = fs_s[1 + (j == 8 ? 61 : 16 + l)],
+                        x6 = fs_s[1 + 24 + l];
+            // ATen starts every accumulator at 0: 0 + x0 is x0 except that it turns -0 into +0
+            float sacc = fadd(0.f, x0);
+            sacc = fadd(sacc, x1); sacc = fadd(sacc, x2); sacc = fadd(sacc, x3); sacc = fadd(sacc, x4); sacc = fadd(sacc, x5);
+            part = j == 8 ? sacc : fadd(sacc, x6);
+        }
+        parts_s[j] = part;
+        __syncthreads();
+        float total;
+        {
+            const float4 p0 = *reinterpret_cast<const float4*>(parts_s), p1 = *reinterpret_cast<const float4*>(parts_s + 4);
+            total = parts_s[8];
+            total = fadd(total, p0.x); total = fadd(total, p0.y); total = fadd(total, p0.z); total = fadd(total, p0.w);
+            total = fadd(total, p1.x); total = fadd(total, p1.y); total = fadd(total, p1.z); total = fadd(total, p1.w);
+        }
+
+        // ---- pdf, cdf
+        float p[4];
+        bool exact = true;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = 4 * j + t;
+            const bool valid = m >= 1 && m <= FAST_NB - 1;
+            p[t] = valid ? fdiv(f[t], total) : 0.f;
+            exact = exact && (!valid || (p[t] >= 3.7252903e-09f && p[t] <= 1.0f));      // 2^-28
+        }
+        const double d0 = (double)p[0], d1 = __dadd_rn(d0, (double)p[1]), d2 = __dadd_rn(d1, (double)p[2]),
+                     d3 = __dadd_rn(d2, (double)p[3]);
+        double incl = d3;
+        incl = __dadd_rn(incl, row_dpp_d<ROW_SHR + 1>(0.0, incl));
+        incl = __dadd_rn(incl, row_dpp_d<ROW_SHR + 2>(0.0, incl));
+        incl = __dadd_rn(incl, row_dpp_d<ROW_SHR + 4>(0.0, incl));
+        incl = __dadd_rn(incl, row_dpp_d<ROW_SHR + 8>(0.0, incl));
+        const double before = row_dpp_d<ROW_SHR + 1>(0.0, incl);
+        float c[4] = {(float)__dadd_rn(before, d0), (float)__dadd_rn(before, d1), (float)__dadd_rn(before, d2),
+                      (float)__dadd_rn(before, d3)};
+        const unsigned long long ex_mask = __ballot(exact && incl < 1.5);
+        const bool row_exact = ((ex_mask >> row0) & 0xffffull) == 0xffffull;
+        {
+            // entry 63 (the lane-15 slot past the end) is the sentinel: a copy of entry 62
+            const float b0 = fmul(0.5f, fadd(z[1], z[0])), b1 = fmul(0.5f, fadd(z[2], z[1])), b2 = fmul(0.5f, fadd(z[3], z[2])),
+                        b3 = fmul(0.5f, fadd(z[4], z[3]));
+            *reinterpret_cast<float4*>(cb_s + 8 * j) = make_float4(c[0], b0, c[1], b1);
+            *reinterpret_cast<float4*>(cb_s + 8 * j + 4) = make_float4(c[2], b2, j == 15 ? c[2] : c[3], j == 15 ? b2 : b3);
+            if (j == 0) cb_s[-1] = b0;
+        }
+        __syncthreads();
+        if (ex_mask != ~0ull) {
+            if (!row_exact && j == 0) {
+                // the sequential float64 sum, each prefix rounded (one lane; the rest of the wave waits)
+                double cs = 0.0;
+                cb_s[0] = 0.f;
+#pragma nounroll
+                for (int i = 1; i <= FAST_NB - 1; ++i) {
+                    cs = __dadd_rn(cs, (double)fdiv(fs_s[i], total));
+                    cb_s[2 * i] = (float)cs;
+                }
+                cb_s[2 * FAST_NB] = cb_s[2 * FAST_NB - 2];
+            }
+            __syncthreads();
+            if (!row_exact) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) c[t] = cb_s[2 * (4 * j + t)];
+            }
+        }
+
+        // ---- how many variates lie below each cdf entry
+        int cnt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float cj = c[t];
+            int k0 = (int)fmul(cj, 127.0f);                                    // NaN -> 0
+            k0 = min(max(k0, 0), FAST_NU);
+            const int km = k0 - 1, kp = k0 + 1;
+            const float um = grid_variate(km), uc = grid_variate(k0), up = grid_variate(kp);      // used for 0 .. 127 only
+            cnt[t] = max(km, 0) + ((km >= 0 && um < cj) ? 1 : 0) + ((k0 < FAST_NU && uc < cj) ? 1 : 0) +
+                     ((kp < FAST_NU && up < cj) ? 1 : 0);                      // 0 .. 128
+        }
+        // #{m : cnt_m <= k} for ascending counts = 1 + the last m with cnt_m <= k: the last entry of every run of equal
+        // counts leaves its number + 1 at slot cnt (one writer per slot, no atomics), a running maximum fills the gaps
+        const int cnt_next = row_dpp_i<ROW_SHL + 1>(cnt[3], cnt[0]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = 4 * j + t;
+            const int nxt = t < 3 ? cnt[t + 1] : cnt_next;
+            const bool writes = m == FAST_NB - 1 || (m < FAST_NB - 1 && nxt != cnt[t]);
+            mark[writes ? cnt[t] : MARK_DUMMY] = m + 1;
+        }
+        __syncthreads();
+        int iv[8];
+        {
+            const int4 ha = *reinterpret_cast<const int4*>(mark + 8 * j), hb = *reinterpret_cast<const int4*>(mark + 8 * j + 4);
+            iv[0] = ha.x; iv[1] = max(iv[0], ha.y); iv[2] = max(iv[1], ha.z); iv[3] = max(iv[2], ha.w);
+            iv[4] = max(iv[3], hb.x); iv[5] = max(iv[4], hb.y); iv[6] = max(iv[5], hb.z); iv[7] = max(iv[6], hb.w);
+            int sc = iv[7];
+            sc = max(sc, row_dpp_i<ROW_SHR + 1>(0, sc));
+            sc = max(sc, row_dpp_i<ROW_SHR + 2>(0, sc));
+            sc = max(sc, row_dpp_i<ROW_SHR + 4>(0, sc));
+            sc = max(sc, row_dpp_i<ROW_SHR + 8>(0, sc));
+            const int lower = row_dpp_i<ROW_SHR + 1>(0, sc);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) iv[t] = max(iv[t], lower);
+        }
+
+        // ---- inverse cdf (the pair at ind - 1 is (cdf[below], cdf[above]) thanks to the sentinels)
+        // A sample lies between the mid-points it was interpolated from (roundings are monotone), and those lie
+        // between coarse depths i - 1, i and i, i + 1: whether depth i is <= the sample is all that is left to look up.
+        float sv[8];
+        bool good = true;
+        unsigned on_edge = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float2* q = reinterpret_cast<const float2*>(cb_s + 2 * iv[t] - 2);
+            const float2 lo = q[0], hi = q[1];                                // (cdf, mid-point) below and above
+            float denom = fsub(hi.x, lo.x);
+            if (denom < 1e-5f) denom = 1.0f;
+            const float tt = fdiv(fsub(u[t], lo.x), denom);
+            sv[t] = fadd(lo.y, fmul(tt, fsub(hi.y, lo.y)));
+            good = good && lo.y <= sv[t] && sv[t] <= hi.y;
+            if (sv[t] == hi.y && iv[t] != FAST_NB) on_edge |= 1u << t;
+        }
+        if (__any(on_edge != 0)) {
+            // a sample equal to its upper mid-point (the last variate when the cdf ends above 1, typically): the
+            // mid-point can round up to the depth above it, so that depth is looked at
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (on_edge & (1u << t)) good = good && zc_s[min(iv[t] + 1, FAST_NZ - 1)] > sv[t];
+        }
+        if (ray_ok) {
+            const size_t o = ray * FAST_NU + 8 * j;
+            if (a.z_samples) {
+                *reinterpret_cast<float4*>(a.z_samples + o) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+                *reinterpret_cast<float4*>(a.z_samples + o + 4) = make_float4(sv[4], sv[5], sv[6], sv[7]);
+            }
+            if (a.inds) {
+                *reinterpret_cast<int4*>(a.inds + o) = make_int4(iv[0], iv[1], iv[2], iv[3]);
+                *reinterpret_cast<int4*>(a.inds + o + 4) = make_int4(iv[4], iv[5], iv[6], iv[7]);
+            }
+        }
+        if (a.z_std) {
+            float ls = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+            ls += row_dpp_f<ROW_SHR + 1>(0.f, ls); ls += row_dpp_f<ROW_SHR + 2>(0.f, ls);
+            ls += row_dpp_f<ROW_SHR + 4>(0.f, ls); ls += row_dpp_f<ROW_SHR + 8>(0.f, ls);
+            const float mean = __shfl(ls, row0 + 15, WAVE) / (float)FAST_NU;
+            float lv = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const float d = sv[t] - mean; lv += d * d; }
+            lv += row_dpp_f<ROW_SHR + 1>(0.f, lv); lv += row_dpp_f<ROW_SHR + 2>(0.f, lv);
+            lv += row_dpp_f<ROW_SHR + 4>(0.f, lv); lv += row_dpp_f<ROW_SHR + 8>(0.f, lv);
+            if (j == 15 && ray_ok) a.z_std[ray] = sqrtf(lv / (float)FAST_NU);
+        }
+
+        // ---- merge with the coarse depths
+        const float s_next = row_dpp_f<ROW_SHL + 1>(sv[7], sv[0]);           // lane 15: its own last
+        good = good && sv[7] <= s_next && cnt[0] <= cnt[1] && cnt[1] <= cnt[2] && (j == 15 || (cnt[2] <= cnt[3] && cnt[3] <= cnt_next));
+#pragma unroll
+        for (int t = 0; t < 7; ++t) good = good && sv[t] <= sv[t + 1];
+        int pos[8];
+        bool le[9];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            le[t] = zc_s[iv[t]] <= sv[t];
+            pos[t] = 8 * j + t + iv[t] + (le[t] ? 1 : 0);
+        }
+        // the samples of a bin that lie below its coarse depth are the first of the bin (samples ascend): the last of
+        // them leaves its number + 1 at the bin's slot (one writer per slot)
+        const int i_next = row_dpp_i<ROW_SHL + 1>(-1, iv[0]);                // lane 15: no bin follows
+        le[8] = row_dpp_i<ROW_SHL + 1>(1, le[0] ? 1 : 0) != 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int inx = t < 7 ? iv[t + 1] : i_next;
+            const bool writes = !le[t] && (inx != iv[t] || le[t + 1]);
+            h2[writes ? iv[t] : H2_DUMMY] = 8 * j + t + 1;
+        }
+        __syncthreads();
+        const unsigned long long good_mask = __ballot(good);
+        const bool row_good = ((good_mask >> row0) & 0xffffull) == 0xffffull;
+        float* out = a.z_sorted + ray * (FAST_NZ + FAST_NU);
+        const int cnt_prev = row_dpp_i<ROW_SHR + 1>(0, cnt[3]);               // lane 0: no entry before its first
+        int rank[4];
+        {
+            const int4 hq = *reinterpret_cast<const int4*>(h2 + 4 * j);
+            rank[0] = 4 * j + max(cnt_prev, hq.x);
+            rank[1] = 4 * j + 1 + max(cnt[0], hq.y);
+            rank[2] = 4 * j + 2 + max(cnt[1], hq.z);
+            rank[3] = 4 * j + 3 + max(cnt[2], hq.w);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) rank[t] = min(rank[t], FAST_NZ + FAST_NU - 1);
+        }
+        __syncthreads();                                        // both marker arrays are read: their space takes the merged row
+        if (row_good) {
+            // scattered 4-byte stores to memory cost more than the rest of the kernel together: scatter in LDS, then
+            // three 16-byte stores per lane that are contiguous across the row
+#pragma unroll
+            for (int t = 0; t < 4; ++t) out_s[rank[t]] = z[t];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) out_s[pos[t]] = sv[t];
+        }
+        __syncthreads();
+        if (row_good && ray_ok) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int q = (16 * i + j) * 4;
+                *reinterpret_cast<float4*>(out + q) = *reinterpret_cast<const float4*>(out_s + q);
+            }
+        }
+        if (good_mask != ~0ull) {
+            // ranks by counting (ties: coarse depths first, then samples by index); everything by index out of LDS,
+            // loops left rolled: this path is for inputs that break the ordering assumptions, it only has to be right
+            // and must not cost the fast path registers
+            __syncthreads();
+            if (!row_good) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) zs_s[8 * j + t] = sv[t];
+            }
+            __syncthreads();
+            if (!row_good && ray_ok) {
+#pragma nounroll
+                for (int t = 0; t < 4; ++t) {
+                    const float v = zc_s[4 * j + t];
+                    int r = 4 * j + t;
+#pragma nounroll
+                    for (int k = 0; k < FAST_NU; ++k) r += (zs_s[k] < v) ? 1 : 0;
+                    out[r] = v;
+                }
+#pragma nounroll
+                for (int t = 0; t < 8; ++t) {
+                    const int own = 8 * j + t;
+                    const float v = zs_s[own];
+                    int r = 0;
+#pragma nounroll
+                    for (int i = 0; i < FAST_NZ; ++i) r += (zc_s[i] <= v) ? 1 : 0;
+#pragma nounroll
+                    for (int k = 0; k < FAST_NU; ++k) {
+                        const float o = zs_s[k];
+                        r += (o < v || (o == v && k < own)) ? 1 : 0;
+                    }
+                    out[r] = v;
+                }
+            }
+        }
     }
 }
 
@@ -379,9 +744,18 @@ extern "C" int nerf_sample_pdf(const float* bins, int bins_stride, int bins_are_
                  "nerf_sample_pdf: row strides shorter than the rows");
     if (z_sorted) NERF_REQUIRE(z_vals && n_z >= 1, "nerf_sample_pdf: z_sorted needs z_vals");
     if (R == 0) return NERF_OK;
-    SamplePdfArgs a{bins, bins_stride, bins_are_z, nb, weights, w_stride, u, n_u, u_per_ray, R,
+    SamplePdfArgs a{0, bins, bins_stride, bins_are_z, nb, weights, w_stride, u, n_u, u_per_ray, R,
                     z_vals, n_z, z_samples, inds, z_sorted, z_std};
     if (nb == FAST_NB && n_u == FAST_NU && !u_per_ray && bins_are_z && z_sorted && z_vals == bins && n_z == FAST_NZ) {
+        // two launches that decide on the device which of them works: the row kernel when the variates are the
+        // regular ascending grid, else the bisection kernel; the other one leaves after reading the 128 variates
+        if ((((uintptr_t)z_samples | (uintptr_t)inds | (uintptr_t)z_sorted) & 15) == 0) {
+            const int n_quads = (R + 3) / 4;
+            hipLaunchKernelGGL(sample_pdf_row_kernel, dim3(n_quads < 16384 ? n_quads : 16384), dim3(WAVE), 0, as_stream(stream), a,
+                               n_quads);
+            NERF_LAUNCH_CHECK();
+            a.skip_if_grid = 1;
+        }
         const size_t fast_shmem = ((size_t)PDF_GROUP * FAST_SC + 64 + FAST_NU + FAST_NZ) * sizeof(float);
         hipLaunchKernelGGL(sample_pdf_fast_kernel, dim3((R + PDF_GROUP - 1) / PDF_GROUP), dim3(WAVE), fast_shmem,
                            as_stream(stream), a);

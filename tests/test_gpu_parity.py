@@ -229,6 +229,54 @@ def test_sample_pdf_api_and_merge(dev, golden):
         assert maxabs(N(std), ref.astype(np.float64).std(-1)) < 2e-6
 
 
+def test_sample_pdf_row_kernel_cases(dev):
+    """The shape render_rays uses (64 depths -> 63 bins, 128 shared variates, merge) on inputs that steer the
+    row-per-ray kernel through its side paths: a ragged last group of rays, all-zero weights (flat pdf, every cdf step
+    below the 1e-5 guard), one-hot weights, weights of very different magnitude (the float64 running sum is then not
+    exact in any order: sequential path), repeated coarse depths (samples equal to mid-points and depths: checked
+    merge), and shared variates that are NOT torch's grid (nearly the grid; unsorted): the bisection kernel must take
+    those.  Everything bit-exact against the oracle."""
+    from nerf_loc_amd import hip
+    rs = np.random.RandomState(23)
+    R, S, NI = 1021, 64, 128
+    z = np.sort(rs.uniform(2, 6, size=(R, S)), -1).astype(F32)
+    wfull = (rs.uniform(0, 1, size=(R, S)) ** 8).astype(F32)
+    wfull[0::11] = 0                                            # flat pdf
+    wfull[1::11] = 0
+    wfull[1::11, 30] = 1.0                                      # one-hot
+    wfull[2::11, 5:9] *= F32(1e12)                              # pdf entries below 2^-28: the exact-sum shortcut must refuse
+    z[3::11, 20:24] = z[3::11, 20:21]                           # repeated depths
+    z[4::11, :] = z[4::11, :1]                                  # a degenerate ray: one depth 64 times
+    wfull[5::11, -2] = 0.0
+    wfull[5::11, 1] = F32(3.0)                                  # mass at the near end
+    grid = orc.linspace01(NI)
+    near_grid = grid.copy()
+    near_grid[37] = np.nextafter(near_grid[37], F32(1))          # one variate off by an ulp: not the grid any more
+    shuffled = grid[rs.permutation(NI)].copy()
+    for name, u in (("grid", grid), ("near", near_grid), ("shuffled", shuffled)):
+        mids = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)
+        ref, ref_i = orc.sample_pdf(mids, wfull[:, 1:-1], u, return_inds=True)
+        wt = T(wfull, dev)
+        zs, inds, zsorted, std = hip.sample_pdf(T(z, dev), wt[:, 1:-1], T(u, dev), bins_are_z=True, z_vals=T(z, dev),
+                                                want_inds=True, want_sorted=True, want_std=True)
+        assert np.array_equal(N(inds), ref_i), name
+        assert np.array_equal(N(zs).view(np.uint32), ref.view(np.uint32)), name
+        assert np.array_equal(N(zsorted), np.sort(np.concatenate([z, ref], -1), -1)), name
+        assert maxabs(N(std), ref.astype(np.float64).std(-1)) < 2e-6, name
+        # without the optional outputs (what render_rays asks for)
+        _, _, zsorted2, _ = hip.sample_pdf(T(z, dev), wt[:, 1:-1], T(u, dev), bins_are_z=True, z_vals=T(z, dev),
+                                           want_samples=False, want_sorted=True, want_std=False)
+        assert np.array_equal(N(zsorted2), N(zsorted)), name
+    # non-finite weights: nothing to compare, but the launch has to come back with every depth written
+    wbad = wfull.copy()
+    wbad[::5, 10] = np.nan
+    wbad[1::5, 12] = np.inf
+    _, _, zsorted, _ = hip.sample_pdf(T(z, dev), T(wbad, dev)[:, 1:-1], T(grid, dev), bins_are_z=True, z_vals=T(z, dev),
+                                      want_samples=False, want_sorted=True, want_std=True)
+    torch.cuda.synchronize()
+    assert N(zsorted).shape == (R, S + NI)
+
+
 # ------------------------------------------------------------------ network
 def test_mlp_fp32_golden(dev, golden):
     g = golden("g4_mlp")
