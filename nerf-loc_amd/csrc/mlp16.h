@@ -356,10 +356,8 @@ void mlp16_bf16_kernel(MlpArgs a) {
         static_assert(KMID >= NFRAGS && KMID < NPAD, "the padding covers the last stage's mid-point");
         st.tick(KMID);
         __builtin_amdgcn_sched_barrier(0);
-        st.fetch(NPAD);
-        st.fetch(NPAD + 1);
-        st.fetch(NPAD + 2);
-        static_assert(PF == 3, "queue refill above");
+#pragma unroll
+        for (int k = 0; k < PF; ++k) st.fetch(NPAD + k);
         __builtin_amdgcn_sched_barrier(0);
         st.end_pass(NPAD);
         NERF_STAMP(t4)
