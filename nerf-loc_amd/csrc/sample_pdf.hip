@@ -1,10 +1,15 @@
 // Hierarchical (inverse-CDF) sampling: sample_pdf (run_nerf_helpers.py:196-239) with the
 // mid-point, sort(cat) and z_std code around it in render_rays (run_nerf.py:397-401, 418).
 //
-// A wavefront takes 64 rays at a time, rows staged in LDS:
-//   weights -> +1e-5 -> sum -> pdf -> cdf        (serial along the ray: one ray per lane, all 64 lanes busy)
-//   u -> searchsorted(right) by binary search over the LDS cdf, one sample per lane per step
-//   samples -> LDS -> merge with the coarse depths by rank -> coalesced store
+// Three kernels, one arithmetic:
+//   sample_pdf_kernel       any sizes, per-ray or shared variates.  A wavefront takes a group of rays; the parts that
+//                           are serial along a ray (sum, pdf, cdf) run one ray per lane on rows staged in LDS, then ray
+//                           by ray: searchsorted(right) by binary search over the LDS cdf, one sample per lane and
+//                           step; samples -> LDS -> merge with the coarse depths by rank -> coalesced store
+//   sample_pdf_fast_kernel  the shape render_rays uses (64 depths -> 63 mid-point bins, 128 shared variates, merge):
+//                           the same with compile-time sizes and unrolled fixed-depth searches
+//   sample_pdf_row_kernel   that shape with torch.linspace variates: one 16-lane row per ray, counting instead of
+//                           searching (described at the kernel)
 //
 // Bit-exactness: indices are the reference's contract, so the float32 arithmetic reproduces
 // ATen's CPU kernels operation by operation:
