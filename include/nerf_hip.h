@@ -42,7 +42,7 @@ extern "C" {
 
 /* Version of this interface (2: the training entry points take a `precision` argument; 3: adds
  * nerf_mlp_backward_static; 4: adds nerf_mlp_forward_objects). */
-#define NERF_HIP_ABI_VERSION 4
+#define NERF_HIP_ABI_VERSION 5
 int nerf_hip_abi_version(void);
 const char* nerf_last_error(void);
 
@@ -66,6 +66,13 @@ int nerf_make_rays(int n_rays, int H, int W, const float* o_in, const float* d_i
                    float near, float far, const float* near_arr, const float* far_arr,
                    int use_viewdirs, int ndc, float ndc_focal, float ndc_near,
                    float* rays_out, void* stream);
+
+/* The pixel grids of n_views poses in one launch: what render_path (run_nerf.py:137-181, nerf_utils.py:107-151) and
+ * Model3DETR.forward (model_3detr.py:619-724) obtain from one get_rays + render() packing per pose.  views [n_views,16]
+ * on the device: c2w (3x4, row-major) then fx, fy, cx, cy; no NDC warp, no second pose.  rays_out [n_views*H*W, 8|11],
+ * view after view.                                                                          */
+int nerf_make_rays_views(int n_views, int H, int W, const float* views, float near, float far, int use_viewdirs,
+                         float* rays_out, void* stream);
 
 /* Stratified depths, run_nerf.py:363-385.  t_vals [S] = linspace(0,1,S) as the host's torch
  * computes it; t_rand [R,S] uniform variates or NULL (perturb = 0).  z_out [R,S].          */

@@ -89,6 +89,32 @@ __global__ __launch_bounds__(256) void make_rays_kernel(MakeRaysArgs a) {
     if (a.use_viewdirs) { r[8] = v[0]; r[9] = v[1]; r[10] = v[2]; }
 }
 
+// The pixel grids of several views in one launch (blockIdx.y = view): views[v] = c2w (3x4, row-major, 12 floats) followed
+// by fx, fy, cx, cy.  Same arithmetic as make_rays_kernel without the NDC warp; view v fills rows [v H W, (v + 1) H W).
+__global__ __launch_bounds__(256) void make_rays_views_kernel(int H, int W, const float* __restrict__ views, float near,
+                                                              float far, int use_viewdirs, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= H * W) return;
+    const float* vw = views + (size_t)blockIdx.y * 16;
+    const int h = n / W, w = n - h * W;
+    float d[3], v[3];
+    pixel_dir(vw, (float)w, (float)h, vw[12], vw[13], vw[14], vw[15], d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = d[k];
+    if (use_viewdirs) {
+        const float nrm = sqrtf(fadd(fadd(fmul(v[0], v[0]), fmul(v[1], v[1])), fmul(v[2], v[2])));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = fdiv(v[k], nrm);
+    }
+    const int cols = use_viewdirs ? 11 : 8;
+    float* r = out + ((size_t)blockIdx.y * H * W + n) * cols;
+    r[0] = vw[3]; r[1] = vw[7]; r[2] = vw[11];
+    r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
+    r[6] = near;
+    r[7] = far;
+    if (use_viewdirs) { r[8] = v[0]; r[9] = v[1]; r[10] = v[2]; }
+}
+
 __global__ __launch_bounds__(256) void z_vals_kernel(const float* __restrict__ rays, int ray_cols, int R,
                                                      int S, const float* __restrict__ t_vals,
                                                      const float* __restrict__ t_rand, int lindisp,
@@ -237,6 +263,20 @@ extern "C" int nerf_make_rays(int n_rays, int H, int W, const float* o_in, const
     a.W_img = W; a.out = rays_out;
     const int block = 256;
     hipLaunchKernelGGL(make_rays_kernel, dim3((n_rays + block - 1) / block), dim3(block), 0, as_stream(stream), a);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+}
+
+extern "C" int nerf_make_rays_views(int n_views, int H, int W, const float* views, float near, float far, int use_viewdirs,
+                                    float* rays_out, void* stream) {
+    NERF_REQUIRE(n_views >= 0 && H >= 1 && W >= 1 && (long long)H * W < (1ll << 31), "nerf_make_rays_views: bad shape %d x %d x %d",
+                 n_views, H, W);
+    NERF_REQUIRE(n_views <= 65535, "nerf_make_rays_views: at most 65535 views per call, got %d", n_views);
+    NERF_REQUIRE(n_views == 0 || (views && rays_out), "nerf_make_rays_views: null pointer");
+    if (n_views == 0) return NERF_OK;
+    const int block = 256;
+    hipLaunchKernelGGL(make_rays_views_kernel, dim3((H * W + block - 1) / block, n_views), dim3(block), 0, as_stream(stream),
+                       H, W, views, near, far, use_viewdirs, rays_out);
     NERF_LAUNCH_CHECK();
     return NERF_OK;
 }

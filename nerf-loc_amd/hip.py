@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "lib", "libnerf_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 4      # 2: training entry points take a precision; 3: nerf_mlp_backward_static; 4: nerf_mlp_forward_objects
+ABI_VERSION = 5      # 2: training entry points take a precision; 3: nerf_mlp_backward_static; 4: nerf_mlp_forward_objects;
+                     # 5: nerf_make_rays_views
 IN_FEATURES, IN_POINTS, IN_RAYS = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
 
@@ -25,6 +26,8 @@ _SIGNATURES = {
     "nerf_hip_abi_version": (ctypes.c_int, []),
     "nerf_last_error": (ctypes.c_char_p, []),
     "nerf_selftest_mfma": (ctypes.c_int, []),
+    "nerf_make_rays_views": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_float, ctypes.c_float,
+                                            ctypes.c_int, _c_float_p, ctypes.c_void_p]),
     "nerf_make_rays": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p,
                                       _c_float_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_int,
@@ -169,6 +172,20 @@ def make_rays(H, W, K, c2w=None, rays_o=None, rays_d=None, near=0.0, far=1.0, us
                                     _ptr(cv), fx, fy, cx, cy, float(near), float(far), _ptr(near_arr), _ptr(far_arr),
                                     int(bool(use_viewdirs)), int(bool(ndc)), fx, float(ndc_near), _ptr(out), _stream(out)),
                "nerf_make_rays")
+    return out
+
+
+def make_rays_views(H, W, views, near, far, use_viewdirs):
+    """The pixel grids of several poses in one launch.  views [V, 16] on the device: c2w (3x4 row-major), fx, fy, cx,
+    cy.  -> [V*H*W, 8|11]."""
+    views = _f32(views, "views")
+    if views.dim() != 2 or views.shape[1] != 16:
+        raise ValueError("make_rays_views: views must be [V, 16], got %s" % (tuple(views.shape),))
+    V = views.shape[0]
+    out = torch.empty((V * int(H) * int(W), 11 if use_viewdirs else 8), dtype=torch.float32, device=views.device)
+    with torch.cuda.device(views.device):
+        _check(lib().nerf_make_rays_views(V, int(H), int(W), _ptr(views), float(near), float(far), int(bool(use_viewdirs)),
+                                          _ptr(out), _stream(out)), "nerf_make_rays_views")
     return out
 
 

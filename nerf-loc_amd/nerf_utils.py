@@ -142,6 +142,25 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, savedir=None, render
     return np.stack(rgbs, 0), np.stack(disps, 0), np.stack(raws, 0), np.stack(depths, 0)
 
 
+def _rays_of_views(H, W, Ks, poses_per_object, ndc, near, far, use_viewdirs):
+    """[sum of poses * H * W, 8|11] rays of all poses of all objects (object o: intrinsics Ks[o]), object after object,
+    pose after pose.  Device-resident poses and plain near / far go through ONE launch (a pose table instead of a
+    get_rays per pose); everything else pose by pose through the general entry."""
+    first = poses_per_object[0][0] if len(poses_per_object) and len(poses_per_object[0]) else None
+    plain = (not ndc and first is not None and isinstance(first, torch.Tensor) and first.is_cuda
+             and not isinstance(near, torch.Tensor) and not isinstance(far, torch.Tensor))
+    if not plain:
+        return torch.cat([_r._build_rays(H, W, Ks[o], None, c2w[:3, :4], ndc, near, far, use_viewdirs, None)[0]
+                          for o in range(len(poses_per_object)) for c2w in poses_per_object[o]], 0)
+    dev = first.device
+    c2w = torch.cat([(p if isinstance(p, torch.Tensor) else torch.stack(list(p)))[:, :3, :4].reshape(-1, 12)
+                     for p in poses_per_object], 0).to(dtype=torch.float32)
+    counts = [len(p) for p in poses_per_object]
+    kf = torch.tensor([[float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])] for K in Ks], dtype=torch.float32)
+    kf = torch.repeat_interleave(kf, torch.tensor(counts), dim=0).to(dev, non_blocking=True)
+    return hip.make_rays_views(H, W, torch.cat([c2w, kf], 1), near, far, use_viewdirs)
+
+
 def render_path_device(render_poses, hwf, K, render_kwargs, render_factor=0):
     """All poses of render_path in ONE ray batch, results left on the device: (rgbs [P,H,W,3], disps [P,H,W],
     raws [P,H,W,S,C] or None, depths [P,H,W]).  The reference renders pose by pose and copies every result to
@@ -153,8 +172,7 @@ def render_path_device(render_poses, hwf, K, render_kwargs, render_factor=0):
     kw = dict(render_kwargs)
     near, far = kw.pop('near', 0.), kw.pop('far', 1.)
     use_viewdirs, ndc = kw.pop('use_viewdirs', False), kw.pop('ndc', False)
-    rays = torch.cat([_r._build_rays(H, W, K, None, c2w[:3, :4], ndc, near, far, use_viewdirs, None)[0]
-                      for c2w in render_poses], 0)
+    rays = _rays_of_views(H, W, [K], [render_poses], ndc, near, far, use_viewdirs)
     ret = batchify_rays(rays, rays.shape[0], **kw)
     P = len(render_poses)
     shp = lambda t: None if t is None else t.reshape([P, H, W] + list(t.shape[1:]))
@@ -175,8 +193,7 @@ def render_path_device_objects(render_poses, hwf, K, render_kwargs_list, render_
     use_viewdirs, ndc = kw.pop('use_viewdirs', False), kw.pop('ndc', False)
     O, P = len(render_kwargs_list), len(render_poses[0])
     Ks = K if (isinstance(K, (list, tuple)) and len(K) == O and np.ndim(K[0]) == 2) else [K] * O
-    rays = torch.cat([_r._build_rays(H, W, Ks[o], None, c2w[:3, :4], ndc, near, far, use_viewdirs, None)[0]
-                      for o in range(O) for c2w in render_poses[o]], 0)
+    rays = _rays_of_views(H, W, Ks, render_poses, ndc, near, far, use_viewdirs)
     kw['network_fn'] = [k['network_fn'] for k in render_kwargs_list]
     ret = batchify_rays(rays, rays.shape[0], **kw)
     shp = lambda t: None if t is None else t.reshape([O, P, H, W] + list(t.shape[1:]))

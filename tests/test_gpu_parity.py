@@ -189,6 +189,25 @@ def test_raw2outputs_5ch_and_large(dev):
     assert (w >= 0).all() and (N(out[2]) <= 1 + 1e-5).all()
 
 
+def test_make_rays_views_equals_pose_by_pose(dev):
+    """Several poses with their own intrinsics in one launch: the same bits as one make_rays per pose."""
+    from nerf_loc_amd import hip
+    H, W = 13, 9
+    poses = [synth.pose_spherical(40.0 * i - 60.0, -25.0 - 3 * i, 3.5 + 0.2 * i)[:3, :4].astype(F32) for i in range(5)]
+    Ks = [np.array([[20.0 + i, 0, 4.5], [0, 21.0 + 2 * i, 6.5], [0, 0, 1]]) for i in range(5)]
+    for vd in (True, False):
+        table = np.stack([np.concatenate([p.reshape(-1), [K[0][0], K[1][1], K[0][2], K[1][2]]]).astype(F32)
+                          for p, K in zip(poses, Ks)])
+        got = N(hip.make_rays_views(H, W, T(table, dev), 0.1, 9.0, vd))
+        want = np.concatenate([N(hip.make_rays(H, W, K, c2w=T(p, dev), near=0.1, far=9.0, use_viewdirs=vd))
+                               for p, K in zip(poses, Ks)], 0)
+        assert got.shape == want.shape == (5 * H * W, 11 if vd else 8)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert hip.make_rays_views(H, W, torch.zeros((0, 16), device=dev), 0.1, 9.0, True).shape == (0, 11)
+    with pytest.raises(ValueError):
+        hip.make_rays_views(H, W, torch.zeros((3, 12), device=dev), 0.1, 9.0, True)
+
+
 # ------------------------------------------------------------------ sample_pdf
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_sample_pdf_bit_exact(dev, golden, tag):
