@@ -37,13 +37,13 @@ FLOP_PER_SAMPLE = 1186816          # 2 x 593 408 MAC (run_nerf_helpers.py:67-119
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks of MI355X
 
 
-def build_scene(device, precision, res):
+def build_scene(device, precision, res, regime="B"):
     from nerf_loc_amd import synth, helpers, render
     H, W, K, c2w, near, far = synth.lego_camera(res, theta=30.0)
 
     def net(seed):
         n = helpers.NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
-        n.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(seed, "B").items()})
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(seed, regime).items()})
         n = n.to(device).requires_grad_(False)
         n.precision = precision
         return n
@@ -149,12 +149,13 @@ def parse_args(argv=None):
     ap.add_argument("--chunk", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="view workload: skip the fp32 and 4M-ray legs that follow the headline region")
+                    help="view workload: skip the fp32, 4M-ray and coarse-only legs that follow the headline region")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank joins the process group, rank 0 prints the world it sees; no "
                          "GPU work (checks the launcher, also on a machine without GPUs)")
-    ap.add_argument("--workload", default="view", choices=["view", "rays4m", "objects", "train"],
-                    help="view: BASELINE configs[1] (default, the headline line); rays4m: configs[2], a 4 194 304-ray "
+    ap.add_argument("--workload", default="view", choices=["view", "rays4m", "objects", "train", "coarse400"],
+                    help="view: BASELINE configs[1] (default, the headline line); coarse400: configs[0], one 400x400 view with the "
+                         "coarse network only; rays4m: configs[2], a 4 194 304-ray "
                          "batch split over the ranks; objects: configs[3], per-object networks dealt to the ranks; "
                          "train: configs[4], 4096-ray training iteration, data parallel")
     return ap.parse_args(argv)
@@ -218,6 +219,22 @@ def make_workload(name, precision, args, rank, world, device):
         def step():
             rays_flat, _ = render._build_rays(H, W, K, None, c2w, False, kwargs["near"], kwargs["far"], True, None)
             rec = ndist.pack_record(render.batchify_rays(rays_flat, args.chunk, **rk), KEYS)
+            return ndist.all_gather_rows(rec, n_rays * world, n_rays) if world > 1 else rec
+    elif name == "coarse400":
+        # BASELINE configs[0], the reference's own CPU-runnable case, on the GPU: coarse network only
+        H, W, K, c2w, kwargs = build_scene(device, precision, 400, regime="A")
+        rk = {k: v for k, v in kwargs.items() if k not in ("near", "far", "use_viewdirs", "ndc")}
+        rk.update(N_importance=0, network_fine=None)
+        n_rays = H * W
+        w.update(n_rays=n_rays, total_rays=n_rays * world, flop_per_ray=64 * FLOP_PER_SAMPLE,
+                 parallelism="ray-shard x%d + 1 all-gather" % world,
+                 desc=("BASELINE configs[0]: one 400x400 view (%d rays/GPU), 64 coarse samples, no importance sampling, "
+                       "D8/W256 L10/4 viewdirs, random-init weights, %s-MFMA mode" % (n_rays, precision)))
+        keys0 = tuple(k for k in KEYS if k in ("rgb_map", "disp_map", "acc_map"))
+
+        def step():
+            rays_flat, _ = render._build_rays(H, W, K, None, c2w, False, kwargs["near"], kwargs["far"], True, None)
+            rec = ndist.pack_record(render.batchify_rays(rays_flat, args.chunk, **rk), keys0)
             return ndist.all_gather_rows(rec, n_rays * world, n_rays) if world > 1 else rec
     elif name == "rays4m":
         total_rays = 4194304
@@ -372,7 +389,8 @@ def main(argv=None):
         # the same view in the reference's own precision, and the 4M-ray strong-scaling batch, in this same run
         w = None      # drops the closure and with it the headline workload's device tensors
         torch.cuda.empty_cache()
-        for tag, wl, prec, st, wu in (("fp32", "view", "fp32", 2, 1), ("strong_4m", "rays4m", "bf16", 2, 1)):
+        for tag, wl, prec, st, wu in (("fp32", "view", "fp32", 2, 1), ("strong_4m", "rays4m", "bf16", 2, 1),
+                                      ("coarse_only_400", "coarse400", "bf16", 10, 2)):
             if tag == "fp32" and precision == "fp32":
                 continue
             x = make_workload(wl, prec, args, rank, world, device)
@@ -404,6 +422,7 @@ def main(argv=None):
                         "kernel": "whole iteration (mlp_f32_train_kernel + mlp_dgrad_f32_kernel + wgrad_kernel), "
                                   "3 x forward FLOPs per sample / step time"}
         metric = {"view": "rendered rays/sec (64+128 samples)", "rays4m": "rendered rays/sec (64+128 samples)",
+                  "coarse400": "rendered rays/sec (64 samples, coarse only)",
                   "objects": "rendered rays/sec (64 samples, coarse only)",
                   "train": "training rays/sec (64+128 samples, fwd+bwd+Adam)"}[args.workload]
         line = {
