@@ -78,15 +78,20 @@ def cpu_baseline(seconds_target=12.0):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
-    # the reference's own CPU-runnable case beside it (BASELINE configs[0]: coarse pass only, 64 samples), bounded too
-    n3 = n2 * 3
+    # the reference's own CPU-runnable case beside it (BASELINE configs[0]: the 400x400 view, random-init weights,
+    # coarse pass only; what the "coarse_only_400" leg renders on the GPU), bounded too
+    H0, W0, K0, c2w0, near0, far0 = synth.lego_camera(400, theta=30.0)
+    o0, d0 = orc.get_rays(H0, W0, K0, c2w0)
+    rays0 = orc.pack_rays(o0, d0, near0, far0, True)
+    n3 = min(n2 * 3, rays0.shape[0])
     t0 = time.time()
-    orc.render_rays(rays[:n3], sc, 64, 0, white_bkgd=True)
+    orc.render_rays(rays0[:n3], synth.make_state_dict(0, "A"), 64, 0, white_bkgd=True)
     dt3 = time.time() - t0
     return {"value": n2 / dt, "unit": "rays/s", "cores": int(cores), "kind": "port", "cpu": cpu_model(),
             "sample": "first %d rays of the same 800x800 view, 64+128 samples, numpy oracle (float32, BLAS threads)" % n2,
             "coarse_only": {"value": n3 / dt3, "unit": "rays/s",
-                            "sample": "first %d rays of the same view, 64 coarse samples only" % n3}}
+                            "sample": "first %d of the 160 000 rays of BASELINE configs[0] (400x400 view, 64 coarse "
+                                      "samples, no importance sampling)" % n3}}
 
 
 def cpu_model():
