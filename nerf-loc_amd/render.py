@@ -228,15 +228,48 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     return ret
 
 
-def warn_nonfinite(ret, skip=()):
-    """The reference's NaN / Inf warning (run_nerf.py:420-422), from one census launch and one read-back."""
-    keys = [k for k in ret if ret[k] is not None and k not in skip and ret[k].dtype == torch.float32 and ret[k].numel()]
-    if not keys:
-        return
-    counts = hip.count_nonfinite([ret[k] for k in keys]).tolist()
+# 'now': the warning is printed before the call returns, like the reference's (one 4-byte-per-map read-back, which
+# makes the host wait for the render).  'deferred': the counts are copied to pinned memory behind the render and
+# printed by the next call that finds them complete (or by flush_nonfinite_reports()); the host never waits.
+NONFINITE_REPORT = 'now'
+_PENDING_REPORTS = []
+
+
+def _print_nonfinite(keys, counts):
     for k, c in zip(keys, counts):
         if c:
             print(f"! [Numerical Error] {k} contains nan or inf.")
+
+
+def flush_nonfinite_reports(wait=True):
+    """Prints the deferred NaN / Inf warnings whose counts have arrived (all of them with wait=True)."""
+    keep = []
+    for ev, host, keys in _PENDING_REPORTS:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            _print_nonfinite(keys, host.tolist())
+        else:
+            keep.append((ev, host, keys))
+    _PENDING_REPORTS[:] = keep
+
+
+def warn_nonfinite(ret, skip=()):
+    """The reference's NaN / Inf warning (run_nerf.py:420-422), from one census launch and one read-back."""
+    keys = [k for k in ret if ret[k] is not None and k not in skip and ret[k].dtype == torch.float32 and ret[k].numel()]
+    if _PENDING_REPORTS:
+        flush_nonfinite_reports(wait=False)
+    if not keys:
+        return
+    counts = hip.count_nonfinite([ret[k] for k in keys])
+    if NONFINITE_REPORT == 'deferred':
+        host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+        host.copy_(counts, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(counts.device))
+        _PENDING_REPORTS.append((ev, host, keys))
+        return
+    _print_nonfinite(keys, counts.tolist())
 
 
 # ---------------------------------------------------------------------------- run_nerf.py:54-134

@@ -768,6 +768,17 @@ def test_nonfinite_census(dev):
     with contextlib.redirect_stdout(buf):
         render.warn_nonfinite({"rgb_map": a, "disp_map": a, "acc_map": b, "none": None}, skip=("disp_map",))
     assert buf.getvalue().count("Numerical Error") == 1 and "rgb_map" in buf.getvalue()
+    # deferred mode: nothing is printed by the call itself, everything by the flush
+    render.NONFINITE_REPORT = 'deferred'
+    try:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            render.warn_nonfinite({"rgb_map": a, "acc_map": b}, skip=())
+            first = buf.getvalue()
+            render.flush_nonfinite_reports()
+        assert first == "" and buf.getvalue().count("Numerical Error") == 1 and not render._PENDING_REPORTS
+    finally:
+        render.NONFINITE_REPORT = 'now'
 
 
 # ------------------------------------------------------------------ full size, size-independent properties
