@@ -23,6 +23,38 @@ __device__ __forceinline__ float fast_exp_neg(float x) {   // exp(-x)
     return __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
 }
 
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int DPP_ROW_SHR = 0x110, DPP_ROW_SHL = 0x100, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
+__device__ __forceinline__ float row_sum_to_last(float s) {      // lane 15 of each row ends up with the row's sum
+    s += dpp_f<DPP_ROW_SHR + 1>(0.f, s);
+    s += dpp_f<DPP_ROW_SHR + 2>(0.f, s);
+    s += dpp_f<DPP_ROW_SHR + 4>(0.f, s);
+    s += dpp_f<DPP_ROW_SHR + 8>(0.f, s);
+    return s;
+}
+// sum over the wavefront, valid in lane 63: row sums, then the totals of rows 0 and 2 into rows 1 and 3, then the total
+// of the lower half into the upper one
+__device__ __forceinline__ float wave_sum_to_last(float s) {
+    s = row_sum_to_last(s);
+    s += dpp_f<DPP_ROW_BCAST15, 0xa>(0.f, s);
+    s += dpp_f<DPP_ROW_BCAST31, 0xc>(0.f, s);
+    return s;
+}
+// inclusive product scan over the wavefront (no LDS traffic: six DPP multiplications)
+__device__ __forceinline__ float wave_prod_scan(float p) {
+    p *= dpp_f<DPP_ROW_SHR + 1>(1.f, p);
+    p *= dpp_f<DPP_ROW_SHR + 2>(1.f, p);
+    p *= dpp_f<DPP_ROW_SHR + 4>(1.f, p);
+    p *= dpp_f<DPP_ROW_SHR + 8>(1.f, p);
+    p *= dpp_f<DPP_ROW_BCAST15, 0xa>(1.f, p);
+    p *= dpp_f<DPP_ROW_BCAST31, 0xc>(1.f, p);
+    return p;
+}
+
 // NCH chunks of 64 samples, all loaded before the first scan so that a wave keeps NCH x 24 B per lane in flight.
 // A wavefront takes RPW consecutive rays (unrolled, so the loads of all of them are in flight together).
 template <int RAW_CH, int NCH, int RPW>
@@ -81,26 +113,20 @@ __global__ __launch_bounds__(256) void raw2outputs_kernel(
         }
         // inclusive product scan of (1 - alpha + 1e-10) over the wave, made exclusive by a shift
         const float one_m = fadd(fsub(1.0f, alpha), 1e-10f);
-        float incl = one_m;
-#pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const float up = __shfl_up(incl, off, WAVE);
-            if (lane >= off) incl *= up;
-        }
-        float excl = __shfl_up(incl, 1, WAVE);
-        if (lane == 0) excl = 1.0f;
+        const float incl = wave_prod_scan(one_m);
+        const float excl = dpp_f<DPP_WAVE_SHR1>(1.0f, incl);      // lane 0 keeps 1
         const float T = carry * excl;
         const float w = alpha * T;
-        carry *= __shfl(incl, WAVE - 1, WAVE);
+        carry *= __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), WAVE - 1));
         if (valid && weights_out) weights_out[(size_t)ray * S + i] = w;
         s_r += w * c0; s_g += w * c1; s_b += w * c2;
         s_depth += w * z;
         s_acc += w;
     }
     }
-    s_r = wave_sum(s_r); s_g = wave_sum(s_g); s_b = wave_sum(s_b);
-    s_depth = wave_sum(s_depth); s_acc = wave_sum(s_acc);
-    if (lane == 0) {
+    s_r = wave_sum_to_last(s_r); s_g = wave_sum_to_last(s_g); s_b = wave_sum_to_last(s_b);
+    s_depth = wave_sum_to_last(s_depth); s_acc = wave_sum_to_last(s_acc);
+    if (lane == WAVE - 1) {
         if (rgb_out) {
             const float bg = white_bkgd ? fsub(1.0f, s_acc) : 0.0f;
             rgb_out[(size_t)ray * 3 + 0] = s_r + bg;
@@ -122,20 +148,6 @@ __global__ __launch_bounds__(256) void raw2outputs_kernel(
 // Rays of at most 64 samples (the coarse pass): a ray is taken by ONE 16-lane row of the wavefront, four consecutive
 // samples per lane, so a wave works on four rays at once and every scan / sum is four DPP row shifts: no cross-row
 // traffic, no LDS.  Loads are 16-byte (raw: one float4 per sample, z: one float4 per lane) when the row length allows.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float old, float src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
-                                                                 CTRL, 0xf, 0xf, false));
-}
-constexpr int DPP_ROW_SHR = 0x110, DPP_ROW_SHL = 0x100;
-__device__ __forceinline__ float row_sum_to_last(float s) {      // lane 15 of each row ends up with the row's sum
-    s += dpp_f<DPP_ROW_SHR + 1>(0.f, s);
-    s += dpp_f<DPP_ROW_SHR + 2>(0.f, s);
-    s += dpp_f<DPP_ROW_SHR + 4>(0.f, s);
-    s += dpp_f<DPP_ROW_SHR + 8>(0.f, s);
-    return s;
-}
-
 template <int RAW_CH, bool VEC>
 __global__ __launch_bounds__(256) void raw2outputs_row_kernel(
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ d_ptr,
