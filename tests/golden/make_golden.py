@@ -27,6 +27,8 @@ Fixtures (all float32 unless noted):
                       run_nerf.py:803-811 written and re-read: key names, optimizer-state layout, and the small
                       tensors after the step (the full checkpoint is 14 MB and is not stored)
   g11_poses.npz       load_llff.py pose pipeline (recentre, spiral, spherify) and load_blender.pose_spherical
+  g12_view_rays.npz   4096 pixels of the benchmark's 800x800 view with the benchmark's networks, coarse + fine,
+                      float32 and float64 reference renders (per-ray maps only)
 """
 import os
 import sys
@@ -457,7 +459,31 @@ def g11():
     save("g11_poses.npz", **out)
 
 
+# ---------------------------------------------------------------- g12
+def g12():
+    """The benchmark's own view and networks at statistical size: 4096 pixels drawn from the 800x800 view of
+    bench.py (lego camera, theta 30), coarse + fine, rendered by the reference in float32 and float64."""
+    H, W, K, c2w, near, far = synth.lego_camera(800, theta=30.0)
+    o, d = refh.get_rays(H, W, K, t(c2w))
+    rs = np.random.RandomState(12)
+    idx = np.sort(rs.choice(H * W, 4096, replace=False))
+    o, d = n(o).reshape(-1, 3)[idx], n(d).reshape(-1, 3)[idx]
+    vd = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    rays = np.concatenate([o, d, np.full((4096, 1), near, np.float32), np.full((4096, 1), far, np.float32), vd], -1).astype(np.float32)
+    out = dict(idx=idx, rays=rays)
+    sc, sf = synth.make_state_dict(0, "B"), synth.make_state_dict(1, "B")
+    kw = dict(N_samples=64, N_importance=128, white_bkgd=True, perturb=0.0, raw_noise_std=0.0, retraw=True)
+    r = run_render_rays(rays, sc, sf, **kw)
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
+        out["f32_" + k] = r[k]
+    r64 = run_render_rays(rays, sc, sf, dtype=torch.float64, **kw)
+    for k in ("rgb_map", "acc_map", "rgb0", "acc0"):
+        out["f64_" + k] = r64[k].astype(np.float32)
+    out["f64_rawlast"] = r64["raw"][:, -1, 3].astype(np.float32)
+    save("g12_view_rays.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for g in which:
         globals()[g]()

@@ -158,6 +158,24 @@ def test_render_rays_coarse_fine(golden, regime):
     assert maxabs(r["z_std"], g[tag + "_z_std"]) < 2e-6
 
 
+def test_render_rays_view_rays(golden):
+    """The oracle on pixels of the benchmark's own view with the benchmark's networks (g12), free-running: the coarse
+    maps within 1e-5 of the reference, the fine maps within 1e-4 (importance samples from the oracle's own coarse
+    weights), on the rays the reference's float64 rerun calls well conditioned."""
+    g = golden("g12_view_rays")
+    n = 384
+    rays = g["rays"][:n]
+    sc, sf = synth.make_state_dict(0, "B"), synth.make_state_dict(1, "B")
+    r = orc.render_rays(rays, sc, 64, 128, sd_fine=sf, white_bkgd=True)
+    mask = np.abs(g["f64_rawlast"][:n]) > 1e-4
+    assert mask.sum() >= n - 2
+    for k in ("rgb0", "acc0"):
+        assert maxabs(r[k], g["f32_" + k][:n]) < 1e-5, k
+    for k in ("rgb_map", "acc_map"):
+        assert maxabs(r[k][mask], g["f32_" + k][:n][mask]) < 1e-4, (k, maxabs(r[k][mask], g["f32_" + k][:n][mask]))
+    assert maxabs(r["z_std"][mask], g["f32_z_std"][:n][mask]) < 2e-4
+
+
 def test_render_rays_variants(golden):
     g = golden("g5_render_rays")
     rays = g["rays"]
