@@ -29,6 +29,7 @@ Fixtures (all float32 unless noted):
   g11_poses.npz       load_llff.py pose pipeline (recentre, spiral, spherify) and load_blender.pose_spherical
   g12_view_rays.npz   4096 pixels of the benchmark's 800x800 view with the benchmark's networks, coarse + fine,
                       float32 and float64 reference renders (per-ray maps only)
+  g13_loc_image.npz   NeRF-Loc's render() on one 240x180 Objectron view (every third pixel of rgb, disp, acc, depth)
 """
 import os
 import sys
@@ -483,7 +484,31 @@ def g12():
     save("g12_view_rays.npz", **out)
 
 
+# ---------------------------------------------------------------- g13
+def g13():
+    """NeRF-Loc's own render() (nerf_loc_coarse_fine/utils/nerf_utils.py) at its real image size: one 240x180 Objectron
+    view, 64 samples, coarse network, near 0.1 / far 9; every third pixel of the four maps is kept."""
+    sys.path.insert(0, "/root/reference/nerf_loc_coarse_fine")
+    cwd = os.getcwd()
+    os.chdir("/root/reference/nerf_loc_coarse_fine")   # it locates nerf-pytorch relative to the cwd
+    try:
+        from utils import nerf_utils as refloc
+    finally:
+        os.chdir(cwd)
+    args = types.SimpleNamespace(nerf_render_rgb=True, nerf_render_depth=True)
+    _, kw_test, _ = refloc.create_nerf_model(args, ckpt_path=None, device="cpu", near=0.1, far=9.0)
+    sc = synth.make_state_dict(100, "B")
+    kw_test["network_fn"].load_state_dict({k: t(v) for k, v in sc.items()})
+    H, W, K, c2w, near, far = synth.objectron_camera(2)
+    with torch.no_grad():
+        rgb, disp, acc, depth, extras = refloc.render(H, W, K, chunk=1024 * 32, c2w=t(c2w), **kw_test)
+    idx = np.arange(0, H * W, 3)
+    pick = lambda v: n(v).reshape(H * W, -1)[idx]
+    save("g13_loc_image.npz", K=K, c2w=c2w, hw=np.array([H, W]), idx=idx, rgb=pick(rgb), disp=pick(disp)[:, 0],
+         acc=pick(acc)[:, 0], depth=pick(depth)[:, 0], raw_sigma_last=n(extras["raw"]).reshape(H * W, 64, 4)[idx, -1, 3])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for g in which:
         globals()[g]()
