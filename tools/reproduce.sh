@@ -1,6 +1,6 @@
 #!/bin/bash
-# Re-creates the files under profiles/ for one round on a GPU box (run from the repository root), in two parts so
-# that each fits one 20-minute box call:
+# Re-creates the files profiles/<tag>_* on a GPU box (run from the repository root; <tag> is the file-name prefix),
+# in two parts so that each fits one 20-minute box call:
 #   bash tools/reproduce.sh r02 a      tests + bench lines
 #   bash tools/reproduce.sh r02 b      rocprofv3 traces, PMC passes, per-kernel bench
 # Needs the library built beforehand (python -c "import __graft_entry__ as g; g.build()").  Every GPU step has its
