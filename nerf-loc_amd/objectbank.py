@@ -83,6 +83,7 @@ class ObjectBank:
         self._pending = {}                                   # key -> Future of (flat, step)
         self._resident = collections.OrderedDict()           # key -> _Entry, least recently used first
         self._lock = threading.Lock()
+        self._miss_lock = threading.Lock()
         self._stream = torch.cuda.Stream(device=self.device)
         self.stats = collections.Counter()
         # pinned staging buffers, recycled: page-locking a fresh 2.4 MB buffer per object costs more than reading it
@@ -157,18 +158,24 @@ class ObjectBank:
         if e is None:
             if path is None:
                 raise KeyError("ObjectBank: %r is not resident and no checkpoint was named" % (key,))
-            self.request(key, ckpt_paths)
-            with self._lock:
-                _, fut = self._pending.pop(key)
-            flat, step = fut.result()
-            e = self._materialise(key, path, flat, step)
-            with self._lock:
-                self._resident[key] = e
-                self._resident.move_to_end(key)
-                self.stats['loads'] += 1
-                while self.capacity is not None and len(self._resident) > self.capacity:
-                    self._resident.popitem(last=False)
-                    self.stats['evictions'] += 1
+            with self._miss_lock:                             # one caller at a time brings objects in
+                with self._lock:
+                    e = self._resident.get(key)               # another caller may have brought it in meanwhile
+                    if e is not None and e.path != path:
+                        e = None
+                if e is None:
+                    self.request(key, ckpt_paths)
+                    with self._lock:
+                        _, fut = self._pending.pop(key)
+                    flat, step = fut.result()
+                    e = self._materialise(key, path, flat, step)
+                    with self._lock:
+                        self._resident[key] = e
+                        self._resident.move_to_end(key)
+                        self.stats['loads'] += 1
+                        while self.capacity is not None and len(self._resident) > self.capacity:
+                            self._resident.popitem(last=False)
+                            self.stats['evictions'] += 1
         cur = torch.cuda.current_stream(self.device)
         for t in e.dev:
             t.record_stream(cur)                              # allocated on the side stream, used on this one

@@ -82,6 +82,24 @@ def test_bank_capacity_and_refusals(dev, tmp_path):
     torch.cuda.synchronize()
     for k, v in net0.state_dict().items():
         assert np.array_equal(v.cpu().numpy(), want[k]), k
+    # several threads asking for the same and for different objects at once
+    import threading
+    bank2 = ObjectBank(kw_test, workers=2)
+    got, errs = {}, []
+
+    def ask(i):
+        try:
+            got[i] = bank2.network(i % 4, paths[i % 4])
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+    threads = [threading.Thread(target=ask, args=(i,)) for i in range(12)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs and len(bank2) == 4 and bank2.stats['loads'] == 4
+    assert all(got[i] is got[i % 4] for i in range(12))
+    bank2.close()
     # a checkpoint of another architecture is refused by name, not loaded
     bad = str(tmp_path / "bad.tar")
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(1, "A", use_viewdirs=False, output_ch=5).items()}
