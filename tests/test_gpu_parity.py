@@ -253,8 +253,9 @@ def test_sample_pdf_row_kernel_cases(dev):
     row-per-ray kernel through its side paths: a ragged last group of rays, all-zero weights (flat pdf, every cdf step
     below the 1e-5 guard), one-hot weights, weights of very different magnitude (the float64 running sum is then not
     exact in any order: sequential path), repeated coarse depths (samples equal to mid-points and depths: checked
-    merge), and shared variates that are NOT torch's grid (nearly the grid; unsorted): the bisection kernel must take
-    those.  Everything bit-exact against the oracle."""
+    merge), and shared variates that are not torch's table: one value off by an ulp (still an ascending near-grid: the
+    row kernel compares against the actual values) and a shuffled table (the bisection kernel must take it).
+    Everything bit-exact against the oracle."""
     from nerf_loc_amd import hip
     rs = np.random.RandomState(23)
     R, S, NI = 1021, 64, 128
@@ -270,7 +271,7 @@ def test_sample_pdf_row_kernel_cases(dev):
     wfull[5::11, 1] = F32(3.0)                                  # mass at the near end
     grid = orc.linspace01(NI)
     near_grid = grid.copy()
-    near_grid[37] = np.nextafter(near_grid[37], F32(1))          # one variate off by an ulp: not the grid any more
+    near_grid[37] = np.nextafter(near_grid[37], F32(1))          # one variate off by an ulp
     shuffled = grid[rs.permutation(NI)].copy()
     for name, u in (("grid", grid), ("near", near_grid), ("shuffled", shuffled)):
         mids = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)
