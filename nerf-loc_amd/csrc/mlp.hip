@@ -722,7 +722,7 @@ static int mlp_forward_impl(const char* who, const void* packed, const void* con
     const long long M = (long long)R * S;
     if (M == 0) return NERF_OK;
     NERF_REQUIRE(M < (1ll << 31) - 512, "%s: at most 2^31 - 512 samples per launch, got %lld", who, M);
-    const int per_tile = precision == NERF_PREC_BF16 ? 256 : 128;
+    const int per_tile = precision == NERF_PREC_BF16 ? m16::TILE16 : 128;
     MlpArgs a;
     a.packed = static_cast<const unsigned char*>(packed);
     a.n_stages = frag_total(precision, use_viewdirs) / STAGE_FRAGS;
@@ -730,17 +730,20 @@ static int mlp_forward_impl(const char* who, const void* packed, const void* con
     a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
     set_sample_divisor(a);
     a.tape = nullptr;
-    a.table = nullptr; a.n_obj = 1; a.tiles_per_obj = 0; a.table_off = 0;
+    a.table = nullptr; a.n_obj = 1; a.tiles_per_obj = 0; a.table_off = 0; a.samples_per_obj = M;
     const long long n_tiles = (M + per_tile - 1) / per_tile;
     long long grid = n_tiles < cu_count() ? n_tiles : cu_count();
     if (table) {
         NERF_REQUIRE(n_objects >= 1 && R % n_objects == 0, "%s: %d rays do not split evenly over %d networks", who, R, n_objects);
         const long long per_obj = M / n_objects;
-        NERF_REQUIRE(per_obj % per_tile == 0, "%s: samples per network (%lld) must be a multiple of %d", who, per_obj, per_tile);
+        // the float32 kernel walks whole tiles; the bf16 kernel bounds every network's last tile by its sample count
+        if (precision != NERF_PREC_BF16)
+            NERF_REQUIRE(per_obj % per_tile == 0, "%s: samples per network (%lld) must be a multiple of %d", who, per_obj, per_tile);
         NERF_REQUIRE(n_objects <= cu_count(), "%s: at most %d networks per launch, got %d", who, cu_count(), n_objects);
         a.table = reinterpret_cast<const unsigned char* const*>(table);
         a.n_obj = n_objects;
-        a.tiles_per_obj = per_obj / per_tile;
+        a.tiles_per_obj = (per_obj + per_tile - 1) / per_tile;
+        a.samples_per_obj = per_obj;
         // a network is served by floor(CUs / networks) workgroups or one more (tile_walk), never by more than it has tiles
         grid = a.tiles_per_obj * n_objects <= cu_count() ? a.tiles_per_obj * n_objects : cu_count();
     }

@@ -13,7 +13,15 @@
 namespace nerf {
 namespace m16 {
 
-constexpr int NCT = 4;                       // 16-column tiles per wave
+// 16-column tiles per wave.  Five, not four: every weight fragment read from LDS, every LDS-DMA byte, every wait and
+// bias read is shared by one more MFMA (the per-fragment overhead is what separates this kernel from a bare MFMA loop),
+// and 80 samples' activations (2 x 160 registers) + encodings + accumulators still fit the 512 registers of a lane.
+constexpr int NCT = 5;
+constexpr int WSAMP = NCT * 16;              // samples per wave and pass
+constexpr int TILE16 = 4 * WSAMP;            // samples per workgroup and pass
+constexpr int PF16 = 2;                      // LDS read-ahead in fragments (a fragment feeds NCT MFMAs = 80 cycles); one
+                                             // more would not fit the registers
+static_assert(PF16 < QD, "fragment queue depth");
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4v bias16(const unsigned char* lds_ring, int tile, int g) {
@@ -71,74 +79,102 @@ __device__ __forceinline__ void encode_raw16(const RawIn& r, int g, float (&pe)[
 // Done by hand the count is exact: NIN vector-memory instructions per pass, in every mode, which the next four
 // stage hand-overs of the ring add to what may stay in flight (Pipe::advance_extra).
 constexpr int IN_FIELDS = 10;
-constexpr int IN_WAVE_BYTES = IN_FIELDS * 64 * 4;
+constexpr int IN_FS = WSAMP * 4;                           // bytes of one field of one wave
+constexpr int IN_WAVE_BYTES = IN_FIELDS * IN_FS;
 constexpr int IN_STAGE_BYTES = 4 * IN_WAVE_BYTES;
 constexpr int LDS16_BYTES = LDS_BYTES + IN_STAGE_BYTES;
-template <bool VD> constexpr int nin() { return VD ? 10 : 7; }
+static_assert(LDS16_BYTES <= 160 * 1024, "LDS of a compute unit");
+template <bool VD> constexpr int nin() { return 2 * (VD ? 10 : 7); }      // two lane groups: samples 0..63 and 64..79
 
 #define NERF_IN_FIRST(va) "s_mov_b32 m0, %[base]\n\ts_nop 0\n\tglobal_load_lds_dword " va ", off\n\t"
-#define NERF_IN_NEXT(va, inc, off) "s_add_u32 m0, m0, " #inc "\n\ts_nop 0\n\tglobal_load_lds_dword " va ", off offset:" #off "\n\t"
-// field j of lane l lands at base + 256 j + 4 l: the LDS address is M0 + instruction offset + 4 l and the same offset
-// is added to the memory address, hence the uneven M0 steps
+#define NERF_IN_NEXT(va, inc, off) "s_add_u32 m0, m0, %[" inc "]\n\ts_nop 0\n\tglobal_load_lds_dword " va ", off offset:" #off "\n\t"
+#define NERF_IN_OPEN "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %[keep], m0\n\ts_mov_b64 %[ex], exec\n\ts_mov_b64 exec, %[mask]\n\t"
+#define NERF_IN_CLOSE "s_mov_b64 exec, %[ex]\n\ts_mov_b32 m0, %[keep]"
+// One lane group (the lanes of `mask`) requests the fields of ITS samples: field j of lane l lands at base + IN_FS j +
+// 4 l.  The LDS address of a load is M0 + instruction offset + 4 l and the same offset is added to the memory address,
+// hence the uneven M0 steps: FS - 4 between consecutive floats of a row (c1), FS - 12 across near / far (c2),
+// FS + 40 / FS + 8 / FS back to a pointer's first float (c3, c5, c0), 4 FS + 20 / 4 FS over unused fields (c4, c6).
 template <bool VD>
-__device__ __forceinline__ void request_inputs(const MlpArgs& a, unsigned m, unsigned wave_block_lds_addr) {
+__device__ __forceinline__ void request_group(const MlpArgs& a, unsigned m, unsigned base, unsigned long long mask) {
     const unsigned ray = sample_ray(a, m);
-    const unsigned base = __builtin_amdgcn_readfirstlane(wave_block_lds_addr);
     unsigned keep;
+    unsigned long long ex;
+#define NERF_IN_CONSTS [c0] "n"(IN_FS), [c1] "n"(IN_FS - 4), [c2] "n"(IN_FS - 12), [c3] "n"(IN_FS + 40), [c4] "n"(4 * IN_FS + 20), \
+                       [c5] "n"(IN_FS + 8), [c6] "n"(4 * IN_FS)
     if (a.mode == NERF_IN_RAYS) {
         const unsigned long long row = reinterpret_cast<unsigned long long>(a.in0) + (unsigned long long)ray * (unsigned)a.ray_cols * 4ull;
         const unsigned long long zz = reinterpret_cast<unsigned long long>(a.in1) + (unsigned long long)m * 4ull;
         if (VD)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %[keep], m0\n\t"
-                         NERF_IN_FIRST("%[row]") NERF_IN_NEXT("%[row]", 252, 4) NERF_IN_NEXT("%[row]", 252, 8)
-                         NERF_IN_NEXT("%[row]", 252, 12) NERF_IN_NEXT("%[row]", 252, 16) NERF_IN_NEXT("%[row]", 252, 20)
-                         NERF_IN_NEXT("%[row]", 244, 32) NERF_IN_NEXT("%[row]", 252, 36) NERF_IN_NEXT("%[row]", 252, 40)
-                         NERF_IN_NEXT("%[zz]", 296, 0)
-                         "s_mov_b32 m0, %[keep]"
-                         : [keep] "=&s"(keep) : [row] "v"(row), [zz] "v"(zz), [base] "s"(base) : "memory", "scc");
+            asm volatile(NERF_IN_OPEN
+                         NERF_IN_FIRST("%[row]") NERF_IN_NEXT("%[row]", "c1", 4) NERF_IN_NEXT("%[row]", "c1", 8)
+                         NERF_IN_NEXT("%[row]", "c1", 12) NERF_IN_NEXT("%[row]", "c1", 16) NERF_IN_NEXT("%[row]", "c1", 20)
+                         NERF_IN_NEXT("%[row]", "c2", 32) NERF_IN_NEXT("%[row]", "c1", 36) NERF_IN_NEXT("%[row]", "c1", 40)
+                         NERF_IN_NEXT("%[zz]", "c3", 0)
+                         NERF_IN_CLOSE
+                         : [keep] "=&s"(keep), [ex] "=&s"(ex)
+                         : [row] "v"(row), [zz] "v"(zz), [base] "s"(base), [mask] "s"(mask), NERF_IN_CONSTS : "memory", "scc");
         else
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %[keep], m0\n\t"
-                         NERF_IN_FIRST("%[row]") NERF_IN_NEXT("%[row]", 252, 4) NERF_IN_NEXT("%[row]", 252, 8)
-                         NERF_IN_NEXT("%[row]", 252, 12) NERF_IN_NEXT("%[row]", 252, 16) NERF_IN_NEXT("%[row]", 252, 20)
-                         NERF_IN_NEXT("%[zz]", 1044, 0)
-                         "s_mov_b32 m0, %[keep]"
-                         : [keep] "=&s"(keep) : [row] "v"(row), [zz] "v"(zz), [base] "s"(base) : "memory", "scc");
+            asm volatile(NERF_IN_OPEN
+                         NERF_IN_FIRST("%[row]") NERF_IN_NEXT("%[row]", "c1", 4) NERF_IN_NEXT("%[row]", "c1", 8)
+                         NERF_IN_NEXT("%[row]", "c1", 12) NERF_IN_NEXT("%[row]", "c1", 16) NERF_IN_NEXT("%[row]", "c1", 20)
+                         NERF_IN_NEXT("%[zz]", "c4", 0)
+                         NERF_IN_CLOSE
+                         : [keep] "=&s"(keep), [ex] "=&s"(ex)
+                         : [row] "v"(row), [zz] "v"(zz), [base] "s"(base), [mask] "s"(mask), NERF_IN_CONSTS : "memory", "scc");
     } else {
         // NERF_IN_POINTS: origin = point, direction and depth are zero (not read back); their slots are filled by
         // repeats of the first load so that the instruction count is the same in both modes
         const unsigned long long pt = reinterpret_cast<unsigned long long>(a.in0) + (unsigned long long)m * 12ull;
         const unsigned long long vd = VD ? reinterpret_cast<unsigned long long>(a.in1) + (unsigned long long)ray * 12ull : pt;
         if (VD)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %[keep], m0\n\t"
-                         NERF_IN_FIRST("%[pt]") NERF_IN_NEXT("%[pt]", 252, 4) NERF_IN_NEXT("%[pt]", 252, 8)
-                         NERF_IN_NEXT("%[pt]", 264, 0) NERF_IN_NEXT("%[pt]", 256, 0) NERF_IN_NEXT("%[pt]", 256, 0)
-                         NERF_IN_NEXT("%[vd]", 256, 0) NERF_IN_NEXT("%[vd]", 252, 4) NERF_IN_NEXT("%[vd]", 252, 8)
-                         NERF_IN_NEXT("%[pt]", 264, 0)
-                         "s_mov_b32 m0, %[keep]"
-                         : [keep] "=&s"(keep) : [pt] "v"(pt), [vd] "v"(vd), [base] "s"(base) : "memory", "scc");
+            asm volatile(NERF_IN_OPEN
+                         NERF_IN_FIRST("%[pt]") NERF_IN_NEXT("%[pt]", "c1", 4) NERF_IN_NEXT("%[pt]", "c1", 8)
+                         NERF_IN_NEXT("%[pt]", "c5", 0) NERF_IN_NEXT("%[pt]", "c0", 0) NERF_IN_NEXT("%[pt]", "c0", 0)
+                         NERF_IN_NEXT("%[vd]", "c0", 0) NERF_IN_NEXT("%[vd]", "c1", 4) NERF_IN_NEXT("%[vd]", "c1", 8)
+                         NERF_IN_NEXT("%[pt]", "c5", 0)
+                         NERF_IN_CLOSE
+                         : [keep] "=&s"(keep), [ex] "=&s"(ex)
+                         : [pt] "v"(pt), [vd] "v"(vd), [base] "s"(base), [mask] "s"(mask), NERF_IN_CONSTS : "memory", "scc");
         else
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %[keep], m0\n\t"
-                         NERF_IN_FIRST("%[pt]") NERF_IN_NEXT("%[pt]", 252, 4) NERF_IN_NEXT("%[pt]", 252, 8)
-                         NERF_IN_NEXT("%[pt]", 264, 0) NERF_IN_NEXT("%[pt]", 256, 0) NERF_IN_NEXT("%[pt]", 256, 0)
-                         NERF_IN_NEXT("%[pt]", 1024, 0)
-                         "s_mov_b32 m0, %[keep]"
-                         : [keep] "=&s"(keep) : [pt] "v"(pt), [base] "s"(base) : "memory", "scc");
+            asm volatile(NERF_IN_OPEN
+                         NERF_IN_FIRST("%[pt]") NERF_IN_NEXT("%[pt]", "c1", 4) NERF_IN_NEXT("%[pt]", "c1", 8)
+                         NERF_IN_NEXT("%[pt]", "c5", 0) NERF_IN_NEXT("%[pt]", "c0", 0) NERF_IN_NEXT("%[pt]", "c0", 0)
+                         NERF_IN_NEXT("%[pt]", "c6", 0)
+                         NERF_IN_CLOSE
+                         : [keep] "=&s"(keep), [ex] "=&s"(ex)
+                         : [pt] "v"(pt), [base] "s"(base), [mask] "s"(mask), NERF_IN_CONSTS : "memory", "scc");
     }
+#undef NERF_IN_CONSTS
 }
 #undef NERF_IN_FIRST
 #undef NERF_IN_NEXT
+#undef NERF_IN_OPEN
+#undef NERF_IN_CLOSE
 
-// the staged inputs of sample s (0..63) of the wave
+// The wave's WSAMP samples starting at `first` (clamped to the last valid sample `last`): lanes 0..63 take samples
+// 0..63, then lanes 0..15 samples 64..79.  nin<VD>() vector-memory instructions, always.
+template <bool VD>
+__device__ __forceinline__ void request_inputs(const MlpArgs& a, unsigned first, unsigned last, int lane,
+                                               unsigned wave_block_lds_addr) {
+    // sample numbers stay below 2^31 (checked by the host), so unsigned arithmetic cannot wrap; a `first` beyond the
+    // end (the request after the last pass) only has to produce valid addresses
+    const unsigned base = __builtin_amdgcn_readfirstlane(wave_block_lds_addr);
+    const unsigned m0 = min(first, last) + lane, m1 = min(first, last) + 64 + (lane & 15);
+    request_group<VD>(a, min(m0, last), base, ~0ull);
+    request_group<VD>(a, min(m1, last), base + 256u, 0xffffull);
+}
+
+// the staged inputs of sample s (0 .. WSAMP - 1) of the wave
 template <bool VD>
 __device__ __forceinline__ void read_inputs(const float* block, int s, bool rays_mode, RawIn& r) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        r.o[k] = block[k * 64 + s];
-        const float d = block[(3 + k) * 64 + s];
+        r.o[k] = block[k * WSAMP + s];
+        const float d = block[(3 + k) * WSAMP + s];
         r.d[k] = rays_mode ? d : 0.0f;
-        r.v[k] = VD ? block[(6 + k) * 64 + s] : 0.0f;
+        r.v[k] = VD ? block[(6 + k) * WSAMP + s] : 0.0f;
     }
-    const float z = block[9 * 64 + s];
+    const float z = block[9 * WSAMP + s];
     r.z = rays_mode ? z : 0.0f;
 }
 
@@ -174,7 +210,7 @@ struct Pending {
     bool relu, live;
 };
 
-// slice sl (0..7) of a finished tile's epilogue: two accumulator registers -> one packed operand dword
+// slice sl (0 .. 2 NCT - 1) of a finished tile's epilogue: two accumulator registers -> one packed operand dword
 __device__ __forceinline__ void epi_slice16(const f32x4v (&accp)[NCT], const Pending& p, int sl) {
     const int ct = sl >> 1, half = sl & 1;
     p.dst[0][ct][p.pdw + half] = pack_pair(accp[ct][2 * half], accp[ct][2 * half + 1], p.relu);
@@ -201,7 +237,7 @@ __device__ __forceinline__ void tile16(Stream& st, int pos, int g, bool staged, 
             else st.p.advance();
         }
         __builtin_amdgcn_sched_barrier(0);
-        st.fetch(k + PF);
+        st.fetch(k + PF16);
         if (s == KS / 2) bias_next = bias16(st.p.lds, bias_next_idx, g);
         __builtin_amdgcn_sched_barrier(0);
         const u32x4* b = s < KPE ? pe[s] : (s < KPE + KH ? hin[s - KPE] : vw[s - KPE - KH]);
@@ -211,18 +247,18 @@ __device__ __forceinline__ void tile16(Stream& st, int pos, int g, bool staged, 
             acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, __builtin_bit_cast(bf16x8, b[ct]), s == 0 ? bias : acc[ct], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (prev.live && EPI_N >= 1 && s >= 1 && s <= EPI_N) {
-                // gaps 0 .. 4 EPI_N - 1 of k-steps 1..EPI_N share the 8 slices evenly
-                const int gap = 4 * (s - 1) + ct, ngap = 4 * (EPI_N >= 1 ? EPI_N : 1);
-                const int lo = (8 * gap + ngap - 1) / ngap, hi = (8 * (gap + 1) + ngap - 1) / ngap;
+                // gaps 0 .. NCT EPI_N - 1 of k-steps 1..EPI_N share the 2 NCT slices evenly
+                const int gap = NCT * (s - 1) + ct, ngap = NCT * (EPI_N >= 1 ? EPI_N : 1);
+                const int lo = (2 * NCT * gap + ngap - 1) / ngap, hi = (2 * NCT * (gap + 1) + ngap - 1) / ngap;
 #pragma unroll
-                for (int sl = lo; sl < (hi < 8 ? hi : 8); ++sl) epi_slice16(accp, prev, sl);
+                for (int sl = lo; sl < (hi < 2 * NCT ? hi : 2 * NCT); ++sl) epi_slice16(accp, prev, sl);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (prev.live && EPI_N < 1) {
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) epi_slice16(accp, prev, sl);
+        for (int sl = 0; sl < 2 * NCT; ++sl) epi_slice16(accp, prev, sl);
     }
     bias = bias_next;
 }
@@ -249,7 +285,7 @@ template <bool VD, int OUT_CH>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp16_bf16_kernel(MlpArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS16_BYTES];
-    const TileWalk tw = tile_walk(a, (a.M + 255) / 256);
+    const TileWalk tw = tile_walk(a, (a.M + TILE16 - 1) / TILE16);
     Stream st;
     pipe_start(st.p, a, lds);
     st.slot0 = 0;
@@ -260,18 +296,18 @@ void mlp16_bf16_kernel(MlpArgs a) {
     constexpr int NPAD = VD ? FRAGS_BF16_VD : FRAGS_BF16_NOVD;      // stream length with the zero padding
 
 #pragma unroll
-    for (int k = 0; k < PF; ++k) st.fetch(k);
+    for (int k = 0; k < PF16; ++k) st.fetch(k);
     f32x4v bias = bias16(st.p.lds, 0, g);
 
     // raw inputs are requested one whole pass ahead (one wave per SIMD: nothing else hides the latency)
     const bool feat_mode = a.mode == NERF_IN_FEATURES, rays_mode = a.mode == NERF_IN_RAYS;
     const bool staged = !feat_mode;
-    const unsigned Mu = (unsigned)a.M;
+    const unsigned s_end = (unsigned)tw.sample_end;      // one past the last sample of this network (< 2^31)
+    const unsigned s_last = s_end - 1;
     const float* in_block = reinterpret_cast<const float*>(lds + LDS_BYTES + wave * IN_WAVE_BYTES);
     const unsigned in_block_addr = (unsigned)(size_t)(lds_ptr_t)(lds + LDS_BYTES) + wave * IN_WAVE_BYTES;
     if (staged) {
-        const unsigned long long m = (unsigned long long)(tw.base + tw.first) * 256ull + wave * 64 + lane;
-        request_inputs<VD>(a, m < Mu ? (unsigned)m : Mu - 1, in_block_addr);
+        request_inputs<VD>(a, (unsigned)tw.sample0 + (unsigned)tw.first * TILE16 + wave * WSAMP, s_last, lane, in_block_addr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // once per launch: the first pass has nothing to hide it under
     }
 
@@ -279,15 +315,15 @@ void mlp16_bf16_kernel(MlpArgs a) {
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, acc_t[6] = {0, 0, 0, 0, 0, 0};
 #endif
     for (long long t = tw.first; t < tw.end; t += tw.stride) {
-        const long long tile = tw.base + t;
+        const unsigned pass0 = (unsigned)tw.sample0 + (unsigned)t * TILE16 + wave * WSAMP;
         NERF_STAMP(t0)
         u32x4 pe[2][NCT], vw[1][NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            const unsigned m = (unsigned)tile * 256u + wave * 64 + ct * 16 + c;
+            const unsigned m = pass0 + ct * 16 + c;
             float pv[16], vv[8];
             if (feat_mode) {
-                load_features16<VD>(a, m < Mu ? m : Mu - 1, g, pv, vv);
+                load_features16<VD>(a, m < s_end ? m : s_last, g, pv, vv);
             } else {
                 RawIn cur;
                 read_inputs<VD>(in_block, ct * 16 + c, rays_mode, cur);
@@ -304,8 +340,8 @@ void mlp16_bf16_kernel(MlpArgs a) {
         }
         if (staged) {
             // always issued, so that the count the ring's waits allow for is exact: past the end, the last sample again
-            const unsigned long long mn = (unsigned long long)(tile + tw.stride) * 256ull + wave * 64 + lane;
-            request_inputs<VD>(a, mn < Mu ? (unsigned)mn : Mu - 1, in_block_addr);
+            // (the last pass of a 2^31-sample launch: pass0 + stride TILE16 < 2^31 + 256 x 320, no wrap)
+            request_inputs<VD>(a, pass0 + (unsigned)tw.stride * TILE16, s_last, lane, in_block_addr);
         }
 
         NERF_STAMP(t1)
@@ -350,21 +386,21 @@ void mlp16_bf16_kernel(MlpArgs a) {
         }
 #undef NERF_L16
         // The zero padding at the end of the stream: nothing to compute, but the ring keeps turning.  Its one mid-stage
-        // position makes the next pass's first stage visible; then the first PF fragments of that pass are queued.
+        // position makes the next pass's first stage visible; then the first PF16 fragments of that pass are queued.
         // (Written out: left as a loop, hipcc does not unroll it and spills the ring state to LDS.)
         constexpr int KMID = (NFRAGS & ~(STAGE_FRAGS - 1)) + STAGE_FRAGS / 2;
         static_assert(KMID >= NFRAGS && KMID < NPAD, "the padding covers the last stage's mid-point");
         st.tick(KMID);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < PF; ++k) st.fetch(NPAD + k);
+        for (int k = 0; k < PF16; ++k) st.fetch(NPAD + k);
         __builtin_amdgcn_sched_barrier(0);
         st.end_pass(NPAD);
         NERF_STAMP(t4)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            const unsigned m = (unsigned)tile * 256u + wave * 64 + ct * 16 + c;
-            if (m < Mu) {
+            const unsigned m = pass0 + ct * 16 + c;
+            if (m < s_end) {
                 if (OUT_CH == 4) {
                     if (g == 0) *reinterpret_cast<float4*>(a.out + (size_t)m * 4) = make_float4(o0[ct], o1[ct], o2[ct], o3[ct]);
                 } else {

@@ -59,6 +59,7 @@ struct MlpArgs {
     const unsigned char* const* table;
     int n_obj;
     long long tiles_per_obj;
+    long long samples_per_obj;     // bf16 inference kernel: a network's samples need not fill its last tile
     size_t table_off;              // byte offset of the stream this kernel reads inside each packed buffer
     // sample index / S without a division (mlp16.h): exact for indices < 2^31, set by set_sample_divisor()
     unsigned div_magic;
@@ -165,13 +166,15 @@ struct Pipe {
 // b / n_obj of the workgroups of that network, every stride-th of that network's tiles.
 struct TileWalk {
     long long base, first, end, stride;      // tile = base + t, t = first, first + stride, ... < end
+    long long sample0, sample_end;           // the samples of the network this workgroup serves: [sample0, sample_end)
 };
 __device__ __forceinline__ TileWalk tile_walk(MlpArgs& a, long long n_tiles) {
-    if (!a.table) return TileWalk{0, (long long)blockIdx.x, n_tiles, (long long)gridDim.x};
+    if (!a.table) return TileWalk{0, (long long)blockIdx.x, n_tiles, (long long)gridDim.x, 0, a.M};
     const int obj = (int)(blockIdx.x % (unsigned)a.n_obj);
     a.packed = a.table[obj] + a.table_off;
     return TileWalk{obj * a.tiles_per_obj, (long long)(blockIdx.x / (unsigned)a.n_obj), a.tiles_per_obj,
-                    (long long)((gridDim.x - obj + a.n_obj - 1) / a.n_obj)};
+                    (long long)((gridDim.x - obj + a.n_obj - 1) / a.n_obj), obj * a.samples_per_obj,
+                    (obj + 1) * a.samples_per_obj};
 }
 
 __device__ __forceinline__ void pipe_start(Pipe& p, const MlpArgs& a, unsigned char* lds) {

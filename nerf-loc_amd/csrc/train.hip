@@ -465,7 +465,7 @@ extern "C" int nerf_mlp_forward_train(const void* packed, int precision, int use
     a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
     set_sample_divisor(a);
     a.tape = nullptr;
-    a.table = nullptr; a.n_obj = 1; a.tiles_per_obj = 0; a.table_off = 0;
+    a.table = nullptr; a.n_obj = 1; a.tiles_per_obj = 0; a.table_off = 0; a.samples_per_obj = M;
     hipStream_t st = as_stream(stream);
     if (precision == NERF_PREC_BF16) {
         a.n_stages = (use_viewdirs ? FRAGS_BF16_VD : FRAGS_BF16_NOVD) / STAGE_FRAGS;

@@ -47,8 +47,8 @@ def _fusable(fn, embed_fn, embeddirs_fn, has_viewdirs):
 
 
 def _query_objects(nets, query_fn, rays, z, has_vd):
-    """Several networks, each evaluating its equal share of the ray batch: one launch when the shares line up with
-    the kernel's tiles (nerf_mlp_forward_objects), else one launch per network on its slice."""
+    """Several networks, each evaluating its equal share of the ray batch: one launch (nerf_mlp_forward_objects); the
+    float32 kernel needs the shares to line up with its 128-sample tiles, else one launch per network on its slice."""
     n, N_rays, S, cols = len(nets), rays.shape[0], z.shape[1], rays.shape[1]
     first = nets[0]
     if N_rays % n:
@@ -61,8 +61,7 @@ def _query_objects(nets, query_fn, rays, z, has_vd):
             raise ValueError("the networks of a batch must share architecture and precision")
     prec = first.precision_code()
     per = N_rays // n
-    tile = 256 if prec == hip.PREC_BF16 else 128
-    if N_rays and (per * S) % tile == 0:
+    if N_rays and (prec == hip.PREC_BF16 or (per * S) % 128 == 0):
         out = hip.mlp_forward_objects([net.packed_weights(prec) for net in nets], prec, first.use_viewdirs,
                                       first.out_channels, hip.IN_RAYS, rays, z, N_rays, S, cols)
     else:
