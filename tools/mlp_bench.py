@@ -43,8 +43,8 @@ for _ in range(a.reps):
 M = a.rays * a.samples
 t = float(np.median(ts))
 fl = 1186816 if vd else 2 * 492032
-print("mlp %s vd=%d: %d samples, median %.3f ms (min %.3f), %.1f TFLOP/s, %.2f us per 256-sample tile per CU, checksum %.6f"
-      % (a.precision, vd, M, t, min(ts), M * fl / t / 1e9, t * 1e3 / (M / 256 / 256), float(out.abs().mean())))
+print("mlp %s vd=%d: %d samples, median %.3f ms (min %.3f), %.1f TFLOP/s, %.2f ns per sample and CU, checksum %.6f"
+      % (a.precision, vd, M, t, min(ts), M * fl / t / 1e9, t * 1e6 / (M / 256), float(out.abs().mean())))
 try:   # diagnostic builds only (NERF_EXP_STAMP): per-block cycle sums of the sections of a pass
     import ctypes
     fn = hip.lib().nerf_debug_read_stamps
