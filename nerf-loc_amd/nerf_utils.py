@@ -267,8 +267,8 @@ def detector_inputs_batch(poses, render_kwargs_list, input_type='nerf', focal_le
     render_poses = [poses[b, :, :3, :4] for b in range(B)]
     out = {}
 
-    def one(scale, tag):
-        Ks = [np.array([[f * scale, 0, 0.5 * W], [0, f * scale, 0.5 * H], [0, 0, 1]]) for f in focals]
+    def one(divisor, tag):
+        Ks = [np.array([[f / divisor, 0, 0.5 * W], [0, f / divisor, 0.5 * H], [0, 0, 1]]) for f in focals]
         rgbs, disps, raws, depths = render_path_device_objects(render_poses, [H, W, focals[0]], Ks, render_kwargs_list)
         if input_type in _DEPTH_TYPES:
             depths, disps = torch.nan_to_num(depths, nan=1.), torch.nan_to_num(disps, nan=1.)
@@ -278,6 +278,6 @@ def detector_inputs_batch(poses, render_kwargs_list, input_type='nerf', focal_le
     rgbs, depths, raws = one(1.0, '')
     out['raws'] = _assemble(input_type, rgbs, depths, raws, depths)
     if focal_length is not None:
-        c_rgbs, c_depths, c_raws = one(1.0 / focal_length, 'coarse_')
+        c_rgbs, c_depths, c_raws = one(focal_length, 'coarse_')       # focal / focal_length, as object by object
         out['coarse_raws'] = _assemble(input_type, c_rgbs, c_depths, c_raws, depths)
     return out
