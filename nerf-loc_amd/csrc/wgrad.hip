@@ -20,18 +20,37 @@ struct WgradArgs {
     float* bpart;                        // [grid][256] column sums of G, or nullptr
 };
 
-// v_mfma_f32_32x32x2_f32 with i = output feature, j = input feature, k = sample: lane (r, h) feeds
-// G[m + h][32 rt + r] and X[m + h][32 ct + r].  Wave w owns output rows 64 w .. 64 w + 63 (N is a multiple of 64).
+// v_mfma_f32_32x32x2_f32 with i = output feature, j = input feature, k = sample.  Which feature an MFMA row or column
+// stands for is free as long as the partial tile is stored accordingly, so a lane takes CONSECUTIVE features and reads
+// them with one wide load: lane (r, h) of wave w feeds G[m + h][64 w + 2 r + i] (i: the wave's two row tiles, one
+// 8-byte load) and X[m + h][128 g + 4 r + e] (column tile 4 g + e, one 16-byte load per group g of four tiles; with
+// fewer than four tiles 2 r + e or r).  Three loads per k-step instead of ten, and the partial tile leaves in 16-byte
+// stores.  N is a multiple of 64, K = 32 CT, ldg even, ldx a multiple of 4 (checked by the host).
+template <int V> struct WgVec { typedef float T __attribute__((ext_vector_type(V))); };
+template <> struct WgVec<1> { typedef float T; };
+
 template <int CT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void wgrad_kernel(WgradArgs a) {
+    constexpr int V = CT < 4 ? CT : 4;             // consecutive input columns of a lane per group
+    constexpr int NG = CT / V;                     // groups of 32 V columns
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = 64 * wave;
+    // N = 128 (views_linears.0) needs two of the four waves for its rows: the other two take the second half of the
+    // workgroup's samples and leave their partial tile in rows 128..255 of the slot, which nobody else writes.
+    const bool halves = a.N == 128;
+    const int half = halves ? wave >> 1 : 0;
+    const int row0 = halves ? 64 * (wave & 1) : 64 * wave;
+    const int prow0 = row0 + 128 * half;           // where the wave's rows go in the partial tile
     float* part = a.part + (size_t)blockIdx.x * 256 * (32 * CT);
     if (row0 >= a.N) return;                       // whole wave: these rows are never read back
-    const long long m0 = (long long)blockIdx.x * a.chunk;
-    const long long m1 = m0 + a.chunk < a.M ? m0 + a.chunk : a.M;
+    long long m0 = (long long)blockIdx.x * a.chunk;
+    long long m1 = m0 + a.chunk < a.M ? m0 + a.chunk : a.M;
+    const long long last_row = m1 - 1;             // a row of the workgroup's range: where clamped requests go
+    if (halves) {
+        const long long mid = m0 + (((m1 - m0) / 2 + 1) & ~1LL);
+        if (half == 0) m1 = mid < m1 ? mid : m1; else m0 = mid < m1 ? mid : m1;
+    }
 
     f32x16 acc[2][CT];
 #pragma unroll
@@ -42,63 +61,109 @@ void wgrad_kernel(WgradArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][ct][e] = 0.0f;
     float bs0 = 0.0f, bs1 = 0.0f;
 
-    // N is a multiple of 64 and K = 32 CT (checked by the host), so only the sample index needs a bound.  Loads
-    // are unconditional from a clamped row and zeroed by a select: no branches in the loop.
-    constexpr int DEPTH = 4;                       // k-steps of operands in flight
-    float ga[DEPTH][2], xb[DEPTH][CT];
+    // Only the sample index needs a bound.  Loads are unconditional from a clamped row and zeroed by a select: no
+    // branches in the loop.  The row pointers advance by addition (two rows per k-step); the requests of a k-step are
+    // issued after the first MFMA pair of an earlier one, pinned there by scheduling barriers, so that address
+    // arithmetic and load issue run in the shadow of the 64-cycle MFMAs and not between the k-steps.
+#ifndef NERF_WG_DEPTH
+#define NERF_WG_DEPTH 8
+#endif
+    constexpr int DEPTH = NERF_WG_DEPTH;           // k-steps of operands in flight
+    static_assert(DEPTH >= 2, "the slot being refilled must not be the one being consumed");
+    static_assert(DEPTH * (1 + NG) <= 63, "more loads in flight than vmcnt can count");
+    // The loads are inline asm and the waits are counted by hand: hipcc's own vmcnt bookkeeping gives up at the loop's
+    // back edge and drains every load in flight once per trip.  A request is 1 + NG loads; when k-step d is consumed
+    // the requests of the DEPTH - 2 k-steps after it are the only ones that may still be under way.
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef typename WgVec<V>::T xvec;
+    constexpr int LOADS = 1 + NG;
+    f32x2v ga[DEPTH];
+    xvec xb[DEPTH][NG];
     bool live[DEPTH];                              // sample of the slot inside [m0, m1); applied when consumed
-    const float* Gp = a.G + row0 + r;
-    const float* Xp = a.X + r;
-    const long long last = m1 - 1;
-    auto load = [&](int slot, long long m) {
-        const long long mm = m + h;
-        const bool ok = mm < m1;
-        const long long mc = ok ? mm : last;
-        const float* gp = Gp + (size_t)mc * a.ldg;
-        const float* xp = Xp + (size_t)mc * a.ldx;
-        ga[slot][0] = gp[0];
-        ga[slot][1] = gp[32];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) xb[slot][ct] = xp[32 * ct];
+    const int len = (int)(m1 - m0);                // samples of this workgroup (a chunk is far below 2^31)
+    const float* const g_last = a.G + row0 + 2 * r + (size_t)last_row * a.ldg;
+    const float* const x_last = a.X + V * r + (size_t)last_row * a.ldx;
+    const float* gq = a.G + row0 + 2 * r + (size_t)(m0 + h) * a.ldg;     // row of the k-step to be requested next
+    const float* xq = a.X + V * r + (size_t)(m0 + h) * a.ldx;
+    const size_t g_step = (size_t)2 * a.ldg, x_step = (size_t)2 * a.ldx;
+    int rel = h;                                   // that row's number within the chunk
+    auto request = [&](int slot) {
+        const bool ok = rel < len;
+        const float* gs = ok ? gq : g_last;
+        const float* xs = ok ? xq : x_last;
         live[slot] = ok;
+        gq += g_step; xq += x_step; rel += 2;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ga[slot]) : "v"(gs) : "memory");
+        if constexpr (V == 4) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xb[slot][0]) : "v"(xs) : "memory");
+            if constexpr (NG == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(xb[slot][1]) : "v"(xs) : "memory");
+        } else if constexpr (V == 2) {
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xb[slot][0]) : "v"(xs) : "memory");
+        } else {
+            asm volatile("global_load_dword %0, %1, off" : "=v"(xb[slot][0]) : "v"(xs) : "memory");
+        }
+    };
+    auto arrived = [&](int slot) {                 // the slot's registers may be read after this point
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH - 2) * LOADS) : "memory");
+        if constexpr (NG == 2) asm volatile("" : "+v"(ga[slot]), "+v"(xb[slot][0]), "+v"(xb[slot][1]));
+        else asm volatile("" : "+v"(ga[slot]), "+v"(xb[slot][0]));
+    };
+    auto x_of = [&](int slot, int ct) -> float {
+        if constexpr (V == 1) return xb[slot][0];
+        else return xb[slot][ct / V][ct % V];
     };
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d) load(d, m0 + 2 * d);
-    for (long long mb = m0; mb < m1; mb += 2 * DEPTH) {
+    for (int d = 0; d < DEPTH - 1; ++d) request(d);
+    for (int mb = 0; mb < len; mb += 2 * DEPTH) {
+        // one fixed AGPR tuple per accumulator across the back edge (without this hipcc swaps two of them every trip)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+a"(acc[i][ct]));
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            const long long m = mb + 2 * d;
-            // the loads of k-step d + 3 go out before the MFMAs of k-step d: keep the compiler from sinking them
-            __builtin_amdgcn_sched_barrier(0);
-            load((d + DEPTH - 1) % DEPTH, m + 2 * (DEPTH - 1));
-            __builtin_amdgcn_sched_barrier(0);
+            arrived(d);
+            request((d + DEPTH - 1) % DEPTH);                      // k-step d + DEPTH - 1
             // beyond the range only G is zeroed: X then comes from the clamped (real, finite) row and meets a zero
             const float g0 = live[d] ? ga[d][0] : 0.0f, g1 = live[d] ? ga[d][1] : 0.0f;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, xb[d][ct], acc[0][ct], 0, 0, 0);
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, xb[d][ct], acc[1][ct], 0, 0, 0);
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x_of(d, ct), acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x_of(d, ct), acc[1][ct], 0, 0, 0);
             }
             bs0 += g0; bs1 += g1;
         }
     }
+    // Requests past the end are still under way.  Every register they will write is an operand of the statement that
+    // waits for them, so none of these registers can serve as a temporary of the epilogue before the wait is over.
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        if constexpr (NG == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ga[d]), "+v"(xb[d][0]), "+v"(xb[d][1]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ga[d]), "+v"(xb[d][0]) :: "memory");
+    }
+    // element e of an accumulator is MFMA row (e & 3) + 8 (e >> 2) + 4 h, i.e. output feature row0 + 2 * that + i
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int e = 0; e < 16; ++e) {
+            const int row = prow0 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * h) + i;
+            float* dst = part + (size_t)row * (32 * CT) + V * r;
+            if constexpr (V == 4) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = row0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                part[(size_t)row * (32 * CT) + 32 * ct + r] = acc[i][ct][e];
+                for (int grp = 0; grp < NG; ++grp)
+                    *reinterpret_cast<float4*>(dst + 128 * grp) = make_float4(acc[i][4 * grp][e], acc[i][4 * grp + 1][e],
+                                                                              acc[i][4 * grp + 2][e], acc[i][4 * grp + 3][e]);
+            } else if constexpr (V == 2) {
+                *reinterpret_cast<float2*>(dst) = make_float2(acc[i][0][e], acc[i][1][e]);
+            } else {
+                dst[0] = acc[i][0][e];
             }
+        }
     }
     if (a.bpart) {
         bs0 += __shfl_xor(bs0, 32, WAVE);
         bs1 += __shfl_xor(bs1, 32, WAVE);
-        if (h == 0) {
-            a.bpart[(size_t)blockIdx.x * 256 + row0 + r] = bs0;
-            a.bpart[(size_t)blockIdx.x * 256 + row0 + 32 + r] = bs1;
-        }
+        if (h == 0) *reinterpret_cast<float2*>(a.bpart + (size_t)blockIdx.x * 256 + prow0 + 2 * r) = make_float2(bs0, bs1);
     }
 }
 
@@ -185,6 +250,8 @@ int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K,
     const int ct = (K + 31) / 32;
     NERF_REQUIRE(N % 64 == 0 && N <= 256 && (K == 32 || K == 64 || K == 128 || K == 256),
                  "weight gradient: unsupported shape %d x %d", N, K);
+    NERF_REQUIRE(ldg % 2 == 0 && ldx % 4 == 0 && ((uintptr_t)G & 7) == 0 && ((uintptr_t)X & 15) == 0,
+                 "weight gradient: rows of G / X must be 8- / 16-byte aligned (ldg %d, ldx %d)", ldg, ldx);
     long long parts = (M + 511) / 512;             // at least 512 samples per workgroup
     if (parts > WG_MAX_PARTS) parts = WG_MAX_PARTS;
     if (parts > cu_count()) parts = cu_count();
@@ -202,11 +269,13 @@ int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K,
         default: hipLaunchKernelGGL(wgrad_kernel<8>, grid, block, 0, st, a); break;
     }
     NERF_LAUNCH_CHECK();
-    ReduceArgs r{ws, (int)parts, 256, 32 * ctp, N, map == 0 ? K : 32 * ct, dW, ld, col_off, map, nullptr, nullptr, nullptr};
+    // N = 128: every slot holds two partial tiles of 128 rows (see the kernel), i.e. 2 x parts tiles of 128 rows
+    const int tiles = N == 128 ? 2 * (int)parts : (int)parts, tile_rows = N == 128 ? 128 : 256;
+    ReduceArgs r{ws, tiles, tile_rows, 32 * ctp, N, map == 0 ? K : 32 * ct, dW, ld, col_off, map, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r.K + 63) / 64, N), dim3(64), 0, st, r);
     NERF_LAUNCH_CHECK();
     if (db) {
-        ReduceArgs rb{a.bpart, (int)parts, 1, 256, 1, N, db, N, 0, 0, nullptr, nullptr, nullptr};
+        ReduceArgs rb{a.bpart, tiles, 1, tile_rows, 1, N, db, N, 0, 0, nullptr, nullptr, nullptr};
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N + 63) / 64, 1), dim3(64), 0, st, rb);
         NERF_LAUNCH_CHECK();
     }
