@@ -63,8 +63,8 @@ void wgrad_kernel(WgradArgs a) {
 
     // Only the sample index needs a bound.  Loads are unconditional from a clamped row and zeroed by a select: no
     // branches in the loop.  The row pointers advance by addition (two rows per k-step); the requests of a k-step are
-    // issued after the first MFMA pair of an earlier one, pinned there by scheduling barriers, so that address
-    // arithmetic and load issue run in the shadow of the 64-cycle MFMAs and not between the k-steps.
+    // issued after the first MFMA pair of an earlier one, so that address arithmetic and load issue run in the shadow
+    // of the 64-cycle MFMAs and not between the k-steps.
 #ifndef NERF_WG_DEPTH
 #define NERF_WG_DEPTH 8
 #endif
@@ -123,11 +123,13 @@ void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             arrived(d);
-            request((d + DEPTH - 1) % DEPTH);                      // k-step d + DEPTH - 1
             // beyond the range only G is zeroed: X then comes from the clamped (real, finite) row and meets a zero
             const float g0 = live[d] ? ga[d][0] : 0.0f, g1 = live[d] ? ga[d][1] : 0.0f;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x_of(d, 0), acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x_of(d, 0), acc[1][0], 0, 0, 0);
+            request((d + DEPTH - 1) % DEPTH);                      // k-step d + DEPTH - 1, under the MFMAs just issued
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
+            for (int ct = 1; ct < CT; ++ct) {
                 acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x_of(d, ct), acc[0][ct], 0, 0, 0);
                 acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x_of(d, ct), acc[1][ct], 0, 0, 0);
             }
@@ -184,7 +186,25 @@ __global__ void wgrad_small_kernel(WsmallArgs a) {
     float s[WS_MAX_N], b[WS_MAX_N];
 #pragma unroll
     for (int o = 0; o < WS_MAX_N; ++o) s[o] = b[o] = 0.f;
-    for (long long m = m0; m < m1; ++m) {
+    // eight samples' loads are issued before the first of them is used (the sums stay in sample order)
+    constexpr int U = 8;
+    long long m = m0;
+    for (; m + U <= m1; m += U) {
+        float x[U], gv[U][WS_MAX_N];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            x[u] = a.X[(size_t)(m + u) * a.K + k];
+            const float* g = a.d_raw + (size_t)(m + u) * a.ldr + a.c0;
+#pragma unroll
+            for (int o = 0; o < WS_MAX_N; ++o) gv[u][o] = o < a.N ? g[o] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int o = 0; o < WS_MAX_N; ++o)
+                if (o < a.N) { s[o] = fmaf(gv[u][o], x[u], s[o]); b[o] += gv[u][o]; }
+    }
+    for (; m < m1; ++m) {
         const float x = a.X[(size_t)m * a.K + k];
         const float* g = a.d_raw + (size_t)m * a.ldr + a.c0;
 #pragma unroll
@@ -207,10 +227,15 @@ struct ReduceArgs {
     const float* x_scale;
     const float* bpart; float* db;                        // optional: block row N adds [n_parts][256] into db[N]
 };
-__global__ void wgrad_reduce_kernel(ReduceArgs a) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+// Block: 64 columns x RED_SPLIT slices of the parts.  A thread adds its slice in part order (eight interleaved chains
+// keep eight loads in flight), the slices are combined in slice order through LDS: the order of additions is fixed.
+constexpr int RED_SPLIT = 4;
+__global__ __launch_bounds__(64 * RED_SPLIT) void wgrad_reduce_kernel(ReduceArgs a) {
+    __shared__ float slice_sum[RED_SPLIT][64];
+    const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx, row = blockIdx.y;
     const bool bias_row = row == a.N && a.db;
-    if (bias_row ? col >= a.N : (col >= a.K || row >= a.N)) return;
+    bool on = !(bias_row ? col >= a.N : (col >= a.K || row >= a.N));
     int dc = col;
     if (a.map == 1) dc = pe_slot_feature(col >> 5, col & 31);
     else if (a.map == 2) dc = view_slot_feature(col >> 4, col & 15);
@@ -218,18 +243,27 @@ __global__ void wgrad_reduce_kernel(ReduceArgs a) {
         const int f = col & 15, hh = (f >> 2) & 1, q = 8 * (col >> 4) + 4 * (f >> 3) + (f & 3);
         dc = a.map == 3 ? pe_slot_feature(hh, q) : view_slot_feature(hh, q);
     }
-    if (dc < 0 && !bias_row) return;
-    const float* p = bias_row ? a.bpart + col : a.part + (size_t)row * a.pcol + col;
-    const size_t stride = bias_row ? 256 : (size_t)a.prow * a.pcol;
-    // eight interleaved chains keep eight loads in flight; the order of additions is fixed
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int i = 0;
-    for (; i + 8 <= a.n_parts; i += 8) {
+    if (dc < 0 && !bias_row) on = false;
+    float sum = 0.f;
+    if (on) {
+        const float* p = bias_row ? a.bpart + col : a.part + (size_t)row * a.pcol + col;
+        const size_t stride = bias_row ? 256 : (size_t)a.prow * a.pcol;
+        const int per = (a.n_parts + RED_SPLIT - 1) / RED_SPLIT;
+        int i = sl * per;
+        const int end = i + per < a.n_parts ? i + per : a.n_parts;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (; i + 8 <= end; i += 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += p[(size_t)(i + j) * stride];
+            for (int j = 0; j < 8; ++j) s[j] += p[(size_t)(i + j) * stride];
+        }
+        for (int j = 0; i < end; ++i, ++j) s[j] += p[(size_t)i * stride];
+        sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
-    for (int j = 0; i < a.n_parts; ++i, ++j) s[j] += p[(size_t)i * stride];
-    float sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    slice_sum[sl][tx] = sum;
+    __syncthreads();
+    if (sl != 0 || !on) return;
+#pragma unroll
+    for (int q = 1; q < RED_SPLIT; ++q) sum += slice_sum[q][tx];
     if (bias_row) { a.db[col] = sum; return; }
     if (a.x_scale) sum *= 1.0f / *a.x_scale;
     a.dst[(size_t)row * a.ld + a.col_off + dc] = sum;
@@ -240,7 +274,7 @@ int launch_wgrad_reduce(const float* ws, int parts, int pcol, int pcol0, int n_r
     ReduceArgs r{ws + pcol0, parts, 256, pcol, n_rows, k_emit, dW, ld, col_off, map, x_scale,
                  ws + WG_BIAS_OFFSET, db};
     const int cols = k_emit > n_rows ? k_emit : n_rows;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cols + 63) / 64, n_rows + (db ? 1 : 0)), dim3(64), 0, st, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cols + 63) / 64, n_rows + (db ? 1 : 0)), dim3(64 * RED_SPLIT), 0, st, r);
     NERF_LAUNCH_CHECK();
     return NERF_OK;
 }
@@ -272,11 +306,11 @@ int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K,
     // N = 128: every slot holds two partial tiles of 128 rows (see the kernel), i.e. 2 x parts tiles of 128 rows
     const int tiles = N == 128 ? 2 * (int)parts : (int)parts, tile_rows = N == 128 ? 128 : 256;
     ReduceArgs r{ws, tiles, tile_rows, 32 * ctp, N, map == 0 ? K : 32 * ct, dW, ld, col_off, map, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r.K + 63) / 64, N), dim3(64), 0, st, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r.K + 63) / 64, N), dim3(64 * RED_SPLIT), 0, st, r);
     NERF_LAUNCH_CHECK();
     if (db) {
         ReduceArgs rb{a.bpart, tiles, 1, tile_rows, 1, N, db, N, 0, 0, nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N + 63) / 64, 1), dim3(64), 0, st, rb);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N + 63) / 64, 1), dim3(64 * RED_SPLIT), 0, st, rb);
         NERF_LAUNCH_CHECK();
     }
     return NERF_OK;
@@ -293,10 +327,10 @@ int launch_wgrad_small(const float* d_raw, int ldr, int c0, int N, const float* 
     hipLaunchKernelGGL(wgrad_small_kernel, dim3((unsigned)parts), dim3(K), 0, st, a);
     NERF_LAUNCH_CHECK();
     ReduceArgs r{ws, (int)parts, 8, K, N, K, dW, K, 0, 0, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K + 63) / 64, N), dim3(64), 0, st, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K + 63) / 64, N), dim3(64 * RED_SPLIT), 0, st, r);
     NERF_LAUNCH_CHECK();
     ReduceArgs rb{a.bpart, (int)parts, 1, 8, 1, N, db, N, 0, 0, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1, 1), dim3(64), 0, st, rb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1, 1), dim3(64 * RED_SPLIT), 0, st, rb);
     NERF_LAUNCH_CHECK();
     return NERF_OK;
 }
