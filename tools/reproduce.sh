@@ -32,6 +32,7 @@ else
   timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/train16_trace" -- python3 tools/train_bench.py --precision bf16 --steps 5 --warmup 2 > "$out/train16_trace.log" 2>&1
   python3 tools/kstats.py "$out/train16_trace" 16 > "$out/train16_kernel_stats.txt"
   bash tools/pmc.sh "$out/pmc_bf16" > "$out/pmc_bf16.log" 2>&1
+  bash tools/pmc_train.sh "$out/pmc_train" > "$out/pmc_train.log" 2>&1
   for p in bf16 fp32; do
     cp "$out/prof_$p/kernel_stats.txt" profiles/${tag}_kernel_stats_$p.txt
     cp "$out/prof_$p/traffic.txt" profiles/${tag}_pmc_traffic_$p.txt
@@ -41,5 +42,6 @@ else
   cp "$out/train_kernel_stats.txt" profiles/${tag}_kernel_stats_train.txt
   cp "$out/train16_kernel_stats.txt" profiles/${tag}_kernel_stats_train_bf16.txt
   cp "$out/pmc_bf16/summary.txt" profiles/${tag}_pmc_mlp_bf16_raw.txt
+  cp "$out/pmc_train/summary.txt" profiles/${tag}_pmc_train_raw.txt
 fi
 echo "profiles/${tag}_* part $part written"
