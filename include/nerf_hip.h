@@ -32,7 +32,8 @@ extern "C" {
 #define NERF_E_UNSUPPORTED (-3)
 
 #define NERF_PREC_F32 0       /* exact float32 MFMA (v_mfma_f32_32x32x2_f32), fmaf-chain numerics */
-#define NERF_PREC_BF16 1      /* bf16 operands, float32 accumulation (v_mfma_f32_32x32x16_bf16) */
+#define NERF_PREC_BF16 1      /* bf16 operands, float32 accumulation (v_mfma_f32_16x16x32_bf16 for   */
+                              /* inference, v_mfma_f32_32x32x16_bf16 in the training kernels)        */
 
 /* what nerf_mlp_forward reads as its input */
 #define NERF_IN_FEATURES 0    /* in0 = already encoded features [M, 63(+27)] (NeRF.forward)        */
