@@ -163,6 +163,11 @@ class NeRF(nn.Module):
         self._pack_cache[prec] = (key, packed)
         return packed
 
+    def weights_changed(self):
+        """Drops the packed copies.  Only needed after writes that bypass the version counters the cache is keyed on
+        (`p.data.mul_(...)`, raw-pointer writes of foreign code); optimizers, `load_state_dict` and `copy_` are seen."""
+        self._pack_cache.clear()        # forward streams of both precisions and the training code's transposed ones
+
     def forward(self, x):
         """x: [..., input_ch + input_ch_views] encoded features -> [..., 4|output_ch]
         (run_nerf_helpers.py:96-119)."""

@@ -949,3 +949,26 @@ def test_detector_inputs_assembly(dev, input_type):
     assert got["raws"].is_cuda and np.array_equal(N(got["raws"]), want)
     assert np.array_equal(N(got["coarse_raws"]), c_want)
     assert not np.isnan(N(got["raws"])).any() or input_type in ("nerf", "rendered_rgb")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_packed_weight_cache_follows_the_parameters(dev, precision):
+    """The kernel reads a re-laid-out copy of the weights, cached on the network: every way the reference's code
+    changes parameters (in-place updates of an optimizer, load_state_dict when a checkpoint is reloaded,
+    run_nerf.py:221-239, 787) must be seen by the next forward."""
+    sd = synth.make_state_dict(3, "A")
+    net = load_net(sd, dev, precision=precision)
+    x = T(np.random.RandomState(5).uniform(-1, 1, (512, 90)).astype(F32), dev)
+    tol = 1e-5 if precision == "fp32" else 2e-2
+    y0 = net(x)
+    assert net.packed_weights() is net.packed_weights()              # unchanged parameters: no re-pack
+    with torch.no_grad():
+        net.rgb_linear.bias.add_(0.5)                                # what an optimizer does
+    y1 = net(x)
+    assert float((y1[:, :3] - y0[:, :3] - 0.5).abs().max()) < tol and torch.equal(y1[:, 3], y0[:, 3])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert torch.equal(net(x), y0)
+    net.alpha_linear.bias.data.add_(0.25)                            # a write behind the version counter's back
+    net.weights_changed()
+    y3 = net(x)
+    assert float((y3[:, 3] - y0[:, 3] - 0.25).abs().max()) < tol and torch.equal(y3[:, :3], y0[:, :3])
