@@ -42,7 +42,7 @@ extern "C" {
                               /* in registers, never written to memory (render_rays)               */
 
 /* Version of this interface (2: the training entry points take a `precision` argument; 3: adds
- * nerf_mlp_backward_static; 4: adds nerf_mlp_forward_objects). */
+ * nerf_mlp_backward_static; 4: adds nerf_mlp_forward_objects; 5: adds nerf_make_rays_views). */
 #define NERF_HIP_ABI_VERSION 5
 int nerf_hip_abi_version(void);
 const char* nerf_last_error(void);
@@ -133,7 +133,9 @@ int nerf_mlp_forward_objects(const void* const* packed_table_dev, int n_objects,
  * or 5; channels 0-2 colour, 3 density), z_vals [R,S], rays_d read from d_ptr with row
  * stride d_stride floats (so rays+3 with stride ray_cols works), noise [R,S] already scaled
  * or NULL.  Outputs rgb [R,3], disp [R], acc [R], depth [R], weights [R,S]; any may be NULL.
- * disp is NaN where acc == 0, like the reference.                                          */
+ * disp is NaN where acc == 0, like the reference.  S = 1 is the reference's degenerate case:
+ * its interval list is then empty (run_nerf.py:283-284), nothing is composited, acc = depth = 0,
+ * disp = NaN, rgb = the background and `weights` (zero columns there) is left untouched.       */
 int nerf_raw2outputs(const float* raw, int raw_ch, const float* z_vals, const float* d_ptr,
                      int d_stride, const float* noise, int R, int S, int white_bkgd,
                      float* rgb, float* disp, float* acc, float* depth, float* weights,

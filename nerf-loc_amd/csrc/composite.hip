@@ -363,6 +363,19 @@ __global__ __launch_bounds__(256) void raw2outputs_bwd_kernel(
     }
 }
 
+// One sample per ray: the reference builds its interval list from the S - 1 differences of the depths and appends the
+// 1e10 tail with the shape of an (empty) slice of them (run_nerf.py:283-284), so for S = 1 the list is empty, every
+// per-sample tensor broadcasts to [R, 0] and the sums run over nothing: acc = depth = 0, disp = 1 / max(1e-10, 0 / 0) =
+// NaN, rgb = the background, and `weights` has no columns.
+__global__ void raw2outputs_single_sample_kernel(int R, int white, float* rgb, float* disp, float* acc, float* depth) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    if (rgb) { const float c = white ? 1.0f : 0.0f; rgb[3 * (size_t)r] = c; rgb[3 * (size_t)r + 1] = c; rgb[3 * (size_t)r + 2] = c; }
+    if (disp) disp[r] = __builtin_nanf("");
+    if (acc) acc[r] = 0.0f;
+    if (depth) depth[r] = 0.0f;
+}
+
 }  // namespace nerf
 
 using namespace nerf;
@@ -376,6 +389,12 @@ extern "C" int nerf_raw2outputs(const float* raw, int raw_ch, const float* z_val
     NERF_REQUIRE(R >= 0 && S >= 1 && d_stride >= 3, "nerf_raw2outputs: bad shape R=%d S=%d d_stride=%d", R, S, d_stride);
     if (raw_ch == 4) NERF_REQUIRE(((uintptr_t)raw & 15) == 0, "nerf_raw2outputs: raw must be 16-byte aligned");
     if (R == 0) return NERF_OK;
+    if (S == 1) {
+        hipLaunchKernelGGL(raw2outputs_single_sample_kernel, dim3((R + 255) / 256), dim3(256), 0, as_stream(stream), R,
+                           white_bkgd, rgb, disp, acc, depth);
+        NERF_LAUNCH_CHECK();
+        return NERF_OK;
+    }
     const int nch = (S + 63) / 64;
     if (nch == 1) {      // a 16-lane row per ray
         const bool vec = raw_ch == 4 && S % 4 == 0 && ((uintptr_t)z_vals & 15) == 0 && (!noise || ((uintptr_t)noise & 15) == 0) &&
@@ -435,6 +454,10 @@ extern "C" int nerf_raw2outputs_backward(const float* raw, int raw_ch, const flo
     }
     if (raw_ch == 4) NERF_REQUIRE(((uintptr_t)d_raw & 15) == 0, "nerf_raw2outputs_backward: d_raw must be 16-byte aligned");
     if (R == 0) return NERF_OK;
+    if (S == 1) {      // nothing is composited from a single sample (see raw2outputs_single_sample_kernel): no gradient
+        NERF_HIP_CHECK(hipMemsetAsync(d_raw, 0, (size_t)R * raw_ch * sizeof(float), as_stream(stream)));
+        return NERF_OK;
+    }
     dim3 grid((R + 3) / 4), block(4 * WAVE);
     const int nch = (S + 63) / 64;
     if (raw_ch == 4) launch_r2o_bwd<4>(nch, grid, block, as_stream(stream), raw, z_vals, d_ptr, d_stride, noise, R, S,

@@ -324,7 +324,8 @@ def raw2outputs(raw, z, d, d_stride, noise=None, white_bkgd=False, want_weights=
     acc = torch.empty((R,), **f)
     depth = torch.empty((R,), **f) if want_depth else None
     disp = torch.empty((R,), **f) if want_depth else None
-    weights = torch.empty((R, S), **f) if want_weights else None
+    # one sample per ray: the reference's interval list is empty and so are its weights (run_nerf.py:283-284)
+    weights = torch.empty((R, S if S > 1 else 0), **f) if want_weights else None
     with torch.cuda.device(dev):
         _check(lib().nerf_raw2outputs(_ptr(raw), ch, _ptr(z), ctypes.c_void_p(d.data_ptr()), int(d_stride),
                                       _ptr(noise), R, S, int(bool(white_bkgd)), _ptr(rgb), _ptr(disp), _ptr(acc),

@@ -30,6 +30,8 @@ Fixtures (all float32 unless noted):
   g12_view_rays.npz   4096 pixels of the benchmark's 800x800 view with the benchmark's networks, coarse + fine,
                       float32 and float64 reference renders (per-ray maps only)
   g13_loc_image.npz   NeRF-Loc's render() on one 240x180 Objectron view (every third pixel of rgb, disp, acc, depth)
+  g14_shape_sweep.npz sample_pdf for 10 bin / sample counts (2 / 1 ... 200 / 300) and raw2outputs for 20 ray lengths
+                      (1 ... 513 samples), a few rays each
 """
 import os
 import sys
@@ -508,7 +510,42 @@ def g13():
          acc=pick(acc)[:, 0], depth=pick(depth)[:, 0], raw_sigma_last=n(extras["raw"]).reshape(H * W, 64, 4)[idx, -1, 3])
 
 
+# ---------------------------------------------------------------- g14
+G14_PDF_SHAPES = ((2, 1), (3, 2), (5, 7), (9, 16), (17, 33), (33, 64), (64, 100), (100, 128), (129, 200), (200, 300))
+G14_COMPOSITE_S = (1, 2, 3, 4, 7, 16, 31, 33, 63, 65, 100, 127, 129, 191, 193, 255, 256, 257, 300, 513)
+
+
+def g14():
+    """Shape sweep: sample_pdf for bin / sample counts from 2 / 1 to 200 / 300 (ATen's row sum takes different
+    vectorised paths by length, and the searchsorted / gather edge cases move with the counts) and raw2outputs for
+    1 to 513 samples per ray; a few rays each."""
+    rs = np.random.RandomState(1414)
+    out = {}
+    for nb, ns in G14_PDF_SHAPES:
+        R = 24
+        bins, w = pdf_inputs(rs, R, nb)
+        tag = "p%d_%d" % (nb, ns)
+        out[tag + "_bins"], out[tag + "_weights"] = bins, w
+        for mode, kw in (("det", dict(det=True)), ("rnd", dict(det=False, pytest=True))):
+            with Recorder(torch, "searchsorted") as rec:
+                smp = refh.sample_pdf(t(bins), t(w), ns, **kw)
+            out["%s_%s_samples" % (tag, mode)] = n(smp)
+            out["%s_%s_inds" % (tag, mode)] = n(rec.out[0]).astype(np.int16)
+    for S in G14_COMPOSITE_S:
+        R = 16
+        raw = rs.normal(size=(R, S, 4)).astype(np.float32)
+        raw[8:] *= np.float32(20.0)
+        raw[14:, :, 3] = -np.abs(raw[14:, :, 3])
+        z = np.sort(rs.uniform(0.1, 9.0, size=(R, S)), -1).astype(np.float32)
+        d = (rs.normal(size=(R, 3)) * rs.uniform(0.5, 2.0, size=(R, 1))).astype(np.float32)
+        out["c%d_raw" % S], out["c%d_z" % S], out["c%d_d" % S] = raw, z, d
+        r = ref.raw2outputs(t(raw), t(z), t(d), white_bkgd=(S % 2 == 1))
+        for name, v in zip(("rgb", "disp", "acc", "weights", "depth"), r):
+            out["c%d_%s" % (S, name)] = n(v)
+    save("g14_shape_sweep.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for g in which:
         globals()[g]()

@@ -140,7 +140,7 @@ def test_training_step_4096_rays_is_linear_in_its_halves(dev):
         loss = helpers.img2mse(ret["rgb_map"], tgt[sl]) + helpers.img2mse(ret["rgb0"], tgt[sl])
         loss.backward()
         grads = [p.grad.clone() for n in nets for p in n.parameters() if p.grad is not None]
-        return float(loss), grads
+        return float(loss.detach()), grads
 
     l_all, g_all = run(slice(0, 4096))
     l_a, g_a = run(slice(0, 2048))

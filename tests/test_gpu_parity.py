@@ -972,3 +972,43 @@ def test_packed_weight_cache_follows_the_parameters(dev, precision):
     net.weights_changed()
     y3 = net(x)
     assert float((y3[:, 3] - y0[:, 3] - 0.25).abs().max()) < tol and torch.equal(y3[:, :3], y0[:, :3])
+
+
+# ------------------------------------------------------------------ shape sweep against the reference (g14)
+PDF_SHAPES = ((2, 1), (3, 2), (5, 7), (9, 16), (17, 33), (33, 64), (64, 100), (100, 128), (129, 200), (200, 300))
+COMPOSITE_S = (1, 2, 3, 4, 7, 16, 31, 33, 63, 65, 100, 127, 129, 191, 193, 255, 256, 257, 300, 513)
+
+
+@pytest.mark.parametrize("nb,ns", PDF_SHAPES)
+def test_sample_pdf_shape_sweep(dev, golden, nb, ns):
+    """Bin and sample counts from 2 / 1 to 200 / 300: indices and samples bit-identical to the reference's."""
+    from nerf_loc_amd import hip
+    g = golden("g14_shape_sweep")
+    tag = "p%d_%d" % (nb, ns)
+    bins, w = g[tag + "_bins"], g[tag + "_weights"]
+    np.random.seed(0)
+    u_rnd = np.random.rand(bins.shape[0], ns).astype(F32)
+    for mode, u in (("det", orc.linspace01(ns)), ("rnd", u_rnd)):
+        zs, inds, _, _ = hip.sample_pdf(T(bins, dev), T(w, dev), T(u, dev), want_inds=True)
+        assert np.array_equal(N(inds).astype(np.int64), g["%s_%s_inds" % (tag, mode)].astype(np.int64)), mode
+        assert np.array_equal(N(zs).view(np.uint32), g["%s_%s_samples" % (tag, mode)].view(np.uint32)), mode
+
+
+@pytest.mark.parametrize("S", COMPOSITE_S)
+def test_raw2outputs_shape_sweep(dev, golden, S):
+    """1 to 513 samples per ray against the reference.  One sample per ray is the reference's degenerate case: the
+    interval list it builds is empty (run_nerf.py:283-284 appends the 1e10 tail with the shape of an empty slice), so
+    nothing is composited: weights [R, 0], acc = depth = 0, disp NaN, rgb the background."""
+    from nerf_loc_amd import render
+    g = golden("g14_shape_sweep")
+    out = render.raw2outputs(T(g["c%d_raw" % S], dev), T(g["c%d_z" % S], dev), T(g["c%d_d" % S], dev),
+                             white_bkgd=(S % 2 == 1))
+    for name, v in zip(("rgb", "disp", "acc", "weights", "depth"), out):
+        ref, v = g["c%d_%s" % (S, name)], N(v)
+        assert v.shape == ref.shape, (name, v.shape, ref.shape)
+        if name == "disp":
+            assert np.array_equal(np.isnan(v), np.isnan(ref))
+            fin = np.isfinite(ref) & (np.abs(ref) < 1e6)
+            assert maxabs(v[fin] / ref[fin], np.ones(fin.sum())) < 2e-5
+        elif ref.size:
+            assert maxabs(v, ref) < 1e-5 * max(1.0, float(np.abs(ref).max())), name

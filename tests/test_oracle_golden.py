@@ -84,6 +84,39 @@ def test_raw2outputs(golden, S):
     assert np.isnan(g["s%d_k_disp" % S][120:]).all()      # the fixture really has the NaN rows
 
 
+# ------------------------------------------------------------------ g14
+PDF_SHAPES = ((2, 1), (3, 2), (5, 7), (9, 16), (17, 33), (33, 64), (64, 100), (100, 128), (129, 200), (200, 300))
+COMPOSITE_S = (1, 2, 3, 4, 7, 16, 31, 33, 63, 65, 100, 127, 129, 191, 193, 255, 256, 257, 300, 513)
+
+
+@pytest.mark.parametrize("nb,ns", PDF_SHAPES)
+def test_sample_pdf_shape_sweep(golden, nb, ns):
+    g = golden("g14_shape_sweep")
+    tag = "p%d_%d" % (nb, ns)
+    bins, w = g[tag + "_bins"], g[tag + "_weights"]
+    np.random.seed(0)
+    u_rnd = np.random.rand(bins.shape[0], ns).astype(F32)
+    for mode, u in (("det", orc.linspace01(ns)), ("rnd", u_rnd)):
+        s, inds = orc.sample_pdf(bins, w, u, return_inds=True)
+        assert np.array_equal(inds, g["%s_%s_inds" % (tag, mode)].astype(np.int64)), mode
+        assert np.array_equal(s.view(np.uint32), g["%s_%s_samples" % (tag, mode)].view(np.uint32)), mode
+
+
+@pytest.mark.parametrize("S", COMPOSITE_S)
+def test_raw2outputs_shape_sweep(golden, S):
+    g = golden("g14_shape_sweep")
+    out = orc.raw2outputs(g["c%d_raw" % S], g["c%d_z" % S], g["c%d_d" % S], white_bkgd=(S % 2 == 1))
+    for name, v in zip(("rgb", "disp", "acc", "weights", "depth"), out):
+        ref = g["c%d_%s" % (S, name)]
+        if name == "disp":
+            fin = np.isfinite(ref) & (np.abs(ref) < 1e6)
+            assert np.array_equal(np.isnan(v), np.isnan(ref))
+            assert maxabs(v[fin] / ref[fin], np.ones(fin.sum())) < 5e-6
+        elif ref.size:      # one sample per ray: the reference composites nothing (weights [R, 0])
+            assert maxabs(v, ref) < 2e-6 * max(1.0, float(np.abs(ref).max())), name
+        assert v.shape == ref.shape
+
+
 # ------------------------------------------------------------------ g3 / g4
 def test_embed(golden):
     g = golden("g3_embed")
