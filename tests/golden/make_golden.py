@@ -30,6 +30,8 @@ Fixtures (all float32 unless noted):
   g12_view_rays.npz   4096 pixels of the benchmark's 800x800 view with the benchmark's networks, coarse + fine,
                       float32 and float64 reference renders (per-ray maps only)
   g13_loc_image.npz   NeRF-Loc's render() on one 240x180 Objectron view (every third pixel of rgb, disp, acc, depth)
+  g15_depths_embed.npz stratified depths of render_rays for 1 ... 300 samples (linear / disparity, with / without the
+                      seeded jitter) and positional encodings for 0, 1, 2, 6, 15 frequencies
   g14_shape_sweep.npz sample_pdf for 10 bin / sample counts (2 / 1 ... 200 / 300) and raw2outputs for 20 ray lengths
                       (1 ... 513 samples), a few rays each
 """
@@ -545,7 +547,52 @@ def g14():
     save("g14_shape_sweep.npz", **out)
 
 
+# ---------------------------------------------------------------- g15
+G15_Z_SAMPLES = (1, 2, 3, 5, 63, 64, 65, 192, 300)
+G15_EMBED_L = (0, 1, 2, 6, 15)
+
+
+def g15():
+    """Stratified depths as render_rays builds them (run_nerf.py:363-385), for 1 to 300 samples, linear in depth and
+    in disparity, with and without the numpy-seeded jitter of the pytest hook: the depths are what render_rays hands
+    to raw2outputs, recorded there (the network is a stand-in that returns zeros).  And the positional encoding for
+    other frequency counts than the two the networks use."""
+    rs = np.random.RandomState(1515)
+    R = 40
+    rays = synth.random_rays(R, seed=15, near=0.1, far=9.0)
+    rays[:, 6] += rs.uniform(0, 1, R).astype(np.float32)
+    rays[:, 7] -= rs.uniform(0, 2, R).astype(np.float32)
+    out = {"rays": rays}
+    zero_net = lambda pts, viewdirs, fn: torch.zeros(tuple(pts.shape[:-1]) + (4,))
+    orig = ref.raw2outputs
+    for S in G15_Z_SAMPLES:
+        for lindisp in (False, True):
+            for perturb in (0.0, 1.0):
+                seen = []
+
+                def spy(raw, z_vals, rays_d, *a, **k):
+                    seen.append(n(z_vals).copy())
+                    return orig(raw, z_vals, rays_d, *a, **k)
+                ref.raw2outputs = spy
+                try:
+                    with torch.no_grad():
+                        ref.render_rays(t(rays), None, zero_net, S, lindisp=lindisp, perturb=perturb, pytest=True)
+                finally:
+                    ref.raw2outputs = orig
+                out["z%d_%s_%s" % (S, "disp" if lindisp else "lin", "jit" if perturb else "det")] = seen[0]
+    x = rs.uniform(-6, 6, size=(64, 3)).astype(np.float32)
+    out["x"] = x
+    for L in G15_EMBED_L:
+        fn, ch = refh.get_embedder(L, 0)
+        assert ch == 3 + 6 * L
+        out["embed%d" % L] = n(fn(t(x)))
+    fn, ch = refh.get_embedder(10, -1)            # i = -1: identity, 3 channels
+    assert ch == 3
+    out["embed_identity"] = n(fn(t(x)))
+    save("g15_depths_embed.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for g in which:
         globals()[g]()

@@ -117,6 +117,30 @@ def test_raw2outputs_shape_sweep(golden, S):
         assert v.shape == ref.shape
 
 
+# ------------------------------------------------------------------ g15
+Z_SAMPLES = (1, 2, 3, 5, 63, 64, 65, 192, 300)
+
+
+@pytest.mark.parametrize("S", Z_SAMPLES)
+def test_depths_shape_sweep(golden, S):
+    g = golden("g15_depths_embed")
+    rays = g["rays"]
+    for lindisp in (False, True):
+        tag = "z%d_%s_" % (S, "disp" if lindisp else "lin")
+        assert np.array_equal(orc.z_vals_for(rays, S, lindisp), g[tag + "det"]), tag
+        z = orc.z_vals_for(rays, S, lindisp, np_rand_like((rays.shape[0], S)))
+        assert maxabs(z, g[tag + "jit"]) < 1e-6, tag
+
+
+def test_embed_other_frequency_counts(golden):
+    g = golden("g15_depths_embed")
+    for L in (0, 1, 2, 6, 15):
+        e = orc.embed(g["x"], L)
+        assert e.shape == g["embed%d" % L].shape == (64, 3 + 6 * L)
+        assert maxabs(e, g["embed%d" % L]) < 3e-7, L
+    assert np.array_equal(g["embed_identity"], g["x"])
+
+
 # ------------------------------------------------------------------ g3 / g4
 def test_embed(golden):
     g = golden("g3_embed")
