@@ -464,10 +464,17 @@ def train_step_grads(rays, target, sd_coarse, sd_fine, N_samples=64, N_importanc
     return loss, out[0], out[1]
 
 
-def render_image(H, W, K, c2w, sd_coarse, near, far, use_viewdirs=True, **kw):
-    """render(H, W, K, c2w=...) of run_nerf.py:69-134: full image, maps shaped [H,W,...]."""
+def render_image(H, W, K, c2w, sd_coarse, near, far, use_viewdirs=True, ndc=False, c2w_staticcam=None, **kw):
+    """render(H, W, K, c2w=...) of run_nerf.py:69-134: full image, maps shaped [H,W,...].  With view directions a
+    static camera supplies the ray geometry while the directions fed to the network stay those of c2w (:102-107);
+    the NDC warp (:112-114, near plane 1) acts on the geometry only."""
     o, d = get_rays(H, W, K, c2w)
-    rays = pack_rays(o, d, near, far, use_viewdirs)
+    view = d
+    if use_viewdirs and c2w_staticcam is not None:
+        o, d = get_rays(H, W, K, c2w_staticcam)
+    if ndc:
+        o, d = ndc_rays(H, W, K[0][0], 1.0, o.reshape(-1, 3), d.reshape(-1, 3))
+    rays = pack_rays(o, d, near, far, use_viewdirs, viewdirs_from=view)
     r = render_rays(rays, sd_coarse, use_viewdirs=use_viewdirs, **kw)
     return {k: v.reshape((H, W) + v.shape[1:]) for k, v in r.items()}
 

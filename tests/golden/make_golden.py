@@ -32,6 +32,9 @@ Fixtures (all float32 unless noted):
   g13_loc_image.npz   NeRF-Loc's render() on one 240x180 Objectron view (every third pixel of rgb, disp, acc, depth)
   g15_depths_embed.npz stratified depths of render_rays for 1 ... 300 samples (linear / disparity, with / without the
                       seeded jitter) and positional encodings for 0, 1, 2, 6, 15 frequencies
+  g16_render_branches.npz render() with the NDC warp, disparity-linear depths, a static camera, NDC + static camera, and a
+                      network without view directions (12 x 16 / 16 x 16 pixels, coarse + fine, float64 mask data,
+                      the reference's importance samples)
   g14_shape_sweep.npz sample_pdf for 10 bin / sample counts (2 / 1 ... 200 / 300) and raw2outputs for 20 ray lengths
                       (1 ... 513 samples), a few rays each
 """
@@ -592,7 +595,59 @@ def g15():
     save("g15_depths_embed.npz", **out)
 
 
+# ---------------------------------------------------------------- g16
+def g16():
+    """render() down its less travelled branches (run_nerf.py:95-123): the NDC warp of forward-facing scenes (near 0,
+    far 1), depths linear in disparity, a static camera for the geometry with view directions from the moving
+    one, both together, and a network without view directions on 8-column rays.  12 x 16 and 16 x 16 pixels, coarse + fine; beside
+    every float32 render the density of the last fine sample from a float64 rerun (conditioning mask of the tests)."""
+    H, W, focal = 12, 16, 14.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    c2w = synth.pose_spherical(20.0, -20.0, 1.0)[:3, :4].copy()
+    c2w_static = synth.pose_spherical(-35.0, -40.0, 1.3)[:3, :4].copy()
+    lego = synth.lego_camera(16, theta=140.0)
+    sc, sf = synth.make_state_dict(160, "B"), synth.make_state_dict(161, "B")
+    sc5 = synth.make_state_dict(162, "B", use_viewdirs=False, output_ch=5, input_ch_views=0)
+    sf5 = synth.make_state_dict(163, "B", use_viewdirs=False, output_ch=5, input_ch_views=0)
+    out = dict(K=K, c2w=c2w, c2w_static=c2w_static, hw=np.array([H, W]), lego_K=lego[2], lego_c2w=lego[3],
+               lego_hw=np.array([lego[0], lego[1]]))
+
+    def run(tag, Hc, Wc, Kc, pose, vd, nets, **over):
+        for dtype, suffix in ((torch.float32, ""), (torch.float64, "64")):
+            net_c = make_model(nets[0], use_viewdirs=vd, output_ch=4 if vd else 5, dtype=dtype)
+            net_f = make_model(nets[1], use_viewdirs=vd, output_ch=4 if vd else 5, dtype=dtype)
+            kw = dict(network_query_fn=query_fn(vd), perturb=0.0, N_importance=128, network_fine=net_f, N_samples=64,
+                      network_fn=net_c, use_viewdirs=vd, white_bkgd=True, raw_noise_std=0.0, ndc=False, lindisp=False,
+                      near=2.0, far=6.0, retraw=True)
+            kw.update(over)
+            if "c2w_staticcam" in kw:
+                kw["c2w_staticcam"] = t(kw["c2w_staticcam"]).to(dtype)
+            if dtype == torch.float64:
+                torch.set_default_dtype(torch.float64)
+            try:
+                with torch.no_grad(), Recorder(ref, "sample_pdf") as rec:
+                    rgb, disp, acc, extras = ref.render(Hc, Wc, Kc, chunk=200, c2w=t(pose).to(dtype), **kw)
+            finally:
+                torch.set_default_dtype(torch.float32)
+            if suffix:
+                out[tag + "_rawlast64"] = n(extras["raw"])[..., -1, 3].astype(np.float32)
+                out[tag + "_rgb64"], out[tag + "_acc64"] = n(rgb).astype(np.float32), n(acc).astype(np.float32)
+            else:
+                out[tag + "_z_samples"] = np.concatenate([n(z) for z in rec.out], 0)      # one entry per chunk
+                out.update({tag + "_rgb": n(rgb), tag + "_disp": n(disp), tag + "_acc": n(acc),
+                            tag + "_rgb0": n(extras["rgb0"]), tag + "_acc0": n(extras["acc0"]),
+                            tag + "_z_std": n(extras["z_std"])})
+
+    run("ndc", H, W, K, c2w, True, (sc, sf), ndc=True, near=0.0, far=1.0)
+    run("lindisp", H, W, K, c2w, True, (sc, sf), near=0.5, far=3.0, lindisp=True)
+    run("static", lego[0], lego[1], lego[2], lego[3], True, (sc, sf), c2w_staticcam=c2w_static)
+    run("ndc_static", H, W, K, c2w, True, (sc, sf), ndc=True, near=0.0, far=1.0, c2w_staticcam=c2w_static)
+    run("novd", lego[0], lego[1], lego[2], lego[3], False, (sc5, sf5))
+    save("g16_render_branches.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15",
+                             "g16"]
     for g in which:
         globals()[g]()

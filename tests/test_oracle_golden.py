@@ -141,6 +141,52 @@ def test_embed_other_frequency_counts(golden):
     assert np.array_equal(g["embed_identity"], g["x"])
 
 
+# ------------------------------------------------------------------ g16
+RENDER_BRANCHES = {
+    # tag: (camera, view directions, network seeds, render kwargs)
+    "ndc": ("small", True, (160, 161), dict(ndc=True, near=0.0, far=1.0)),
+    "lindisp": ("small", True, (160, 161), dict(near=0.5, far=3.0, lindisp=True)),
+    "static": ("lego", True, (160, 161), dict(near=2.0, far=6.0, static=True)),
+    "ndc_static": ("small", True, (160, 161), dict(ndc=True, near=0.0, far=1.0, static=True)),
+    "novd": ("lego", False, (162, 163), dict(near=2.0, far=6.0)),
+}
+
+
+def render_branch_inputs(g, tag):
+    cam, vd, seeds, kw = RENDER_BRANCHES[tag]
+    kw = dict(kw)
+    if cam == "small":
+        H, W = [int(v) for v in g["hw"]]
+        K, c2w = g["K"], g["c2w"]
+    else:
+        H, W = [int(v) for v in g["lego_hw"]]
+        K, c2w = g["lego_K"], g["lego_c2w"]
+    arch = {} if vd else dict(use_viewdirs=False, output_ch=5, input_ch_views=0)
+    sds = [synth.make_state_dict(s, "B", **arch) for s in seeds]
+    static = g["c2w_static"] if kw.pop("static", False) else None
+    return H, W, K, c2w, vd, sds, static, kw
+
+
+@pytest.mark.parametrize("tag", sorted(RENDER_BRANCHES))
+def test_render_branches(golden, tag):
+    """render() with the NDC warp, disparity-linear depths, a static camera and a network without view directions."""
+    g = golden("g16_render_branches")
+    H, W, K, c2w, vd, sds, static, kw = render_branch_inputs(g, tag)
+    near, far = kw.pop("near"), kw.pop("far")
+    r = orc.render_image(H, W, K, c2w, sds[0], near, far, use_viewdirs=vd, c2w_staticcam=static, N_samples=64,
+                         N_importance=128, sd_fine=sds[1], white_bkgd=True, z_samples_override=g[tag + "_z_samples"], **kw)
+    ok = np.abs(g[tag + "_rawlast64"]) > 1e-3           # conditioning mask from the reference's float64 run
+    assert ok.mean() > 0.9
+    assert maxabs(r["rgb0"], g[tag + "_rgb0"]) < 2e-5 and maxabs(r["acc0"], g[tag + "_acc0"]) < 2e-5
+    # the oracle's own importance samples: ill-conditioned in nearly empty bins (see test_render_rays_coarse_fine)
+    dz = np.abs(r["z_samples_own"].reshape(-1, 128) - g[tag + "_z_samples"])
+    assert dz.max() < 5e-3 * (far - near) and (dz > 2e-5 * (far - near)).mean() < 0.2
+    # the fine pass on the reference's importance samples
+    e = max(maxabs(r["rgb_map"][ok], g[tag + "_rgb"][ok]), maxabs(r["acc_map"][ok], g[tag + "_acc"][ok]))
+    print("%s: fine maps max abs err %.2e on the reference's samples, %d of %d rays masked" % (tag, e, (~ok).sum(), ok.size))
+    assert e < 2e-5
+
+
 # ------------------------------------------------------------------ g3 / g4
 def test_embed(golden):
     g = golden("g3_embed")
