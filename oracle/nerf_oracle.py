@@ -444,13 +444,14 @@ def mlp_backward(sd, feat, d_raw, use_viewdirs=True, bf16=False):
 
 
 def train_step_grads(rays, target, sd_coarse, sd_fine, N_samples=64, N_importance=128, white_bkgd=True, t_rand=None,
-                     u=None, noise0=None, noise1=None):
+                     u=None, noise0=None, noise1=None, use_viewdirs=True):
     """Loss img2mse(rgb_map, target) + img2mse(rgb0, target) (run_nerf.py:776-785) and its gradients with respect
-    to both networks.  Returns (loss, grads_coarse, grads_fine)."""
+    to both networks.  Returns (loss, grads_coarse, grads_fine).  use_viewdirs=False: the architecture with
+    output_linear (4 or 5 rows) on 8-column rays."""
     r = render_rays(rays, sd_coarse, N_samples, N_importance, sd_fine=sd_fine, white_bkgd=white_bkgd, t_rand=t_rand,
-                    u=u, noise0=noise0, noise1=noise1, retraw=True)
+                    u=u, noise0=noise0, noise1=noise1, retraw=True, use_viewdirs=use_viewdirs)
     R = rays.shape[0]
-    d, vd = rays[:, 3:6], rays[:, 8:11]
+    d, vd = rays[:, 3:6], (rays[:, 8:11] if use_viewdirs else None)
     loss = img2mse(r["rgb_map"].astype(np.float64), target) + img2mse(r["rgb0"].astype(np.float64), target)
     out = []
     for raw, z, rgb, noise, sd in ((r["raw0"], r["z_vals0"], r["rgb0"], noise0, sd_coarse),
@@ -459,8 +460,11 @@ def train_step_grads(rays, target, sd_coarse, sd_fine, N_samples=64, N_importanc
         d_raw = raw2outputs_backward(raw, z, d, noise, white_bkgd, g_rgb=g_rgb)
         S = z.shape[1]
         pts = (rays[:, None, 0:3] + d[:, None, :] * z[:, :, None]).reshape(-1, 3)
-        feat = np.concatenate([embed(pts, 10), embed(np.repeat(vd, S, 0), 4)], -1)
-        out.append(mlp_backward(sd, feat, d_raw.reshape(-1, 4)))
+        if use_viewdirs:
+            feat = np.concatenate([embed(pts, 10), embed(np.repeat(vd, S, 0), 4)], -1)
+        else:
+            feat = embed(pts, 10)
+        out.append(mlp_backward(sd, feat, d_raw.reshape(-1, raw.shape[-1]), use_viewdirs=use_viewdirs))
     return loss, out[0], out[1]
 
 

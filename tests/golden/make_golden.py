@@ -35,6 +35,7 @@ Fixtures (all float32 unless noted):
   g16_render_branches.npz render() with the NDC warp, disparity-linear depths, a static camera, NDC + static camera, and a
                       network without view directions (12 x 16 / 16 x 16 pixels, coarse + fine, float64 mask data,
                       the reference's importance samples)
+  g17_train_step_novd.npz loss and gradients of one training step of the architecture without view directions
   g14_shape_sweep.npz sample_pdf for 10 bin / sample counts (2 / 1 ... 200 / 300) and raw2outputs for 20 ray lengths
                       (1 ... 513 samples), a few rays each
 """
@@ -646,8 +647,58 @@ def g16():
     save("g16_render_branches.npz", **out)
 
 
+# ---------------------------------------------------------------- g17
+def g17():
+    """One training step of the architecture without view directions (output_linear with 5 rows, as create_nerf builds
+    it when N_importance > 0: run_nerf.py:193) on 8-column rays: loss and gradients from the reference's autograd."""
+    rays = synth.random_rays(96, seed=17)[:, :8].copy()
+    rs = np.random.RandomState(1717)
+    target = rs.uniform(0, 1, size=(96, 3)).astype(np.float32)
+    arch = dict(use_viewdirs=False, output_ch=5, input_ch_views=0)
+    def step(dtype):
+        net_c = make_model(synth.make_state_dict(170, "B", **arch), use_viewdirs=False, output_ch=5, dtype=dtype)
+        net_f = make_model(synth.make_state_dict(171, "B", **arch), use_viewdirs=False, output_ch=5, dtype=dtype)
+        torch.set_default_dtype(dtype)
+        try:
+            r = ref.render_rays(t(rays).to(dtype), net_c, query_fn(False), N_samples=64, N_importance=128,
+                                network_fine=net_f, white_bkgd=True, retraw=True, perturb=0.0, raw_noise_std=0.0)
+            l1 = refh.img2mse(r["rgb_map"], t(target).to(dtype))
+            l0 = refh.img2mse(r["rgb0"], t(target).to(dtype))
+            loss = l1 + l0
+            loss.backward()
+        finally:
+            torch.set_default_dtype(torch.float32)
+        return net_c, net_f, loss, l1
+
+    net_c, net_f, loss, l1 = step(torch.float32)
+    out = dict(rays=rays, target=target, loss=n(loss), psnr=n(refh.mse2psnr(l1)))
+    # the same step in float64: how far the reference's own float32 gradients are from exact ones
+    c64, f64, loss64, _ = step(torch.float64)
+    out["loss64"] = n(loss64)
+    for pre, net in (("c", c64), ("f", f64)):
+        for k, p in net.named_parameters():
+            if p.grad is not None and (k.endswith("bias") or k.startswith("output_linear")):
+                out["%s_grad64_%s" % (pre, k)] = n(p.grad)
+        out[pre + "_grad64_pts0w"] = n(net.pts_linears[0].weight.grad)
+        out[pre + "_grad64_pts5w_sub"] = n(net.pts_linears[5].weight.grad[::8, ::11])
+    for pre, net in (("c", net_c), ("f", net_f)):
+        names, norms = [], []
+        for k, p in net.named_parameters():
+            if p.grad is None:                      # views_linears: constructed, never used without view directions
+                continue
+            names.append(k)
+            norms.append(float(p.grad.norm()))
+            if k.endswith("bias") or k.startswith("output_linear"):
+                out["%s_grad_%s" % (pre, k)] = n(p.grad)
+        out[pre + "_names"] = np.array(names)
+        out[pre + "_gradnorm"] = np.array(norms, np.float64)
+        out[pre + "_grad_pts0w"] = n(net.pts_linears[0].weight.grad)
+        out[pre + "_grad_pts5w_sub"] = n(net.pts_linears[5].weight.grad[::8, ::11])
+    save("g17_train_step_novd.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15",
-                             "g16"]
+                             "g16", "g17"]
     for g in which:
         globals()[g]()

@@ -401,6 +401,45 @@ def test_train_step_gradients(golden):
     _check_grads(g, "stoch", "f", gf)
 
 
+def novd_gradient_errors(g, pre, grads):
+    """For every gradient tensor g17 holds: (name, error of `grads` against the reference's float32 autograd, the
+    reference's own float32-vs-float64 difference, error against its float64 autograd), all relative to the tensor's
+    largest entry."""
+    rows = []
+    named = [(n, "%s_grad_%s" % (pre, n), "%s_grad64_%s" % (pre, n), (slice(None),)) for n in [str(x) for x in g[pre + "_names"]]]
+    named += [("pts_linears.0.weight", pre + "_grad_pts0w", pre + "_grad64_pts0w", (slice(None), slice(None))),
+              ("pts_linears.5.weight", pre + "_grad_pts5w_sub", pre + "_grad64_pts5w_sub",
+               (slice(None, None, 8), slice(None, None, 11)))]
+    for name, k32, k64, sl in named:
+        if k32 not in g:
+            continue
+        got = np.asarray(grads[name], np.float64)[sl]
+        scale = max(float(np.abs(g[k64]).max()), 1e-12)
+        rows.append((name, float(np.abs(got - g[k32]).max()) / scale, float(np.abs(g[k32] - g[k64]).max()) / scale,
+                     float(np.abs(got - g[k64]).max()) / scale))
+    return rows
+
+
+def test_train_step_gradients_without_view_directions(golden):
+    """The architecture with output_linear (5 rows) on 8-column rays against the reference's autograd (g17), which
+    ran the step in float32 and in float64.  The gradients of this step are small (1e-5) sums of 6144 terms that
+    cancel, so the reference's float32 result is itself up to 2e-3 (relative) from its float64 one (the oracle, float32
+    forward and float64 backward, sits between them): the coarse network is held to both at 1e-4 or twice the
+    reference's own difference, whichever is larger; the fine
+    network (importance samples that move with the last bit of the coarse weights) to 5e-3."""
+    g = golden("g17_train_step_novd")
+    arch = dict(use_viewdirs=False, output_ch=5, input_ch_views=0)
+    sc, sf = synth.make_state_dict(170, "B", **arch), synth.make_state_dict(171, "B", **arch)
+    loss, gc, gf = orc.train_step_grads(g["rays"], g["target"], sc, sf, use_viewdirs=False)
+    assert abs(loss - float(g["loss"])) < 1e-6 and abs(loss - float(g["loss64"])) < 1e-6
+    names = [str(n) for n in g["c_names"]]
+    assert not any(n.startswith("views_linears") for n in names) and len(names) == 18
+    for name, e32, own, e64 in novd_gradient_errors(g, "c", gc):
+        assert e32 < max(1e-4, 2 * own) and e64 < max(1e-4, 2 * own), (name, e32, own, e64)
+    for name, e32, own, e64 in novd_gradient_errors(g, "f", gf):
+        assert e32 < 5e-3, (name, e32, own, e64)
+
+
 def test_bf16_restatement_of_the_network_backward():
     """The bf16 variant of the oracle (checker of the bf16 training kernels; the reference has no such mode):
     rounding is round-to-nearest-even on the upper 16 bits, and the gradients stay near the float64 ones."""
