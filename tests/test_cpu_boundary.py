@@ -234,13 +234,14 @@ def test_dropin_alias_modules_resolve_to_the_engine(tmp_path):
     (other / "misc.py").write_text("MARK = 'reference utils.misc'\n")
     (other / "nerf_utils.py").write_text("raise ImportError('the reference copy must lose to dropin/utils/nerf_utils.py')\n")
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(1, %r)\n"
-            "import run_nerf, run_multi_nerf, run_nerf_helpers\n"
+            "import run_nerf, run_multi_nerf, run_multi_nerf_scannet, run_nerf_helpers\n"
             "from run_nerf_helpers import *\n"
             "from utils.nerf_utils import create_nerf_model, load_nerf_model, render_path\n"
             "import utils.misc\n"
             "assert utils.misc.MARK == 'reference utils.misc'\n"
             "assert create_nerf_model.__module__.startswith('nerf_loc_amd')\n"
             "assert NeRF.__module__.endswith('helpers') and run_multi_nerf.run_network is run_nerf.run_network\n"
+            "assert run_multi_nerf_scannet.render_rays is run_nerf.render_rays\n"
             "for n in ('render', 'render_rays', 'batchify', 'batchify_rays', 'raw2outputs', 'create_nerf', 'render_path',\n"
             "          'sample_pdf', 'get_embedder', 'get_rays', 'get_rays_np', 'ndc_rays', 'img2mse', 'mse2psnr', 'to8b'):\n"
             "    assert callable(getattr(run_nerf, n)), n\n"
