@@ -121,8 +121,7 @@ int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int ou
  * run_multi_nerf.py:560-572) as NeRF-Loc consumes it, a batch of scans each rendered with its own network
  * (model_3detr.py:619-724).  The flat batch holds n_objects equal parts: rays [o R/n, (o+1) R/n) (and their samples)
  * are evaluated with network o.  packed_table_dev: DEVICE array of n_objects pointers to packed streams
- * (nerf_mlp_pack; same precision, use_viewdirs and output_ch for all).  R must divide evenly; with NERF_PREC_F32 the
- * samples per network, R/n * S, must be a multiple of 128; n_objects at most the number of compute units.  Every other argument as for nerf_mlp_forward; results are bit-identical to n_objects separate
+ * (nerf_mlp_pack; same precision, use_viewdirs and output_ch for all).  R must divide evenly; n_objects at most the number of compute units.  Every other argument as for nerf_mlp_forward; results are bit-identical to n_objects separate
  * nerf_mlp_forward calls.                                                                                   */
 int nerf_mlp_forward_objects(const void* const* packed_table_dev, int n_objects, int precision, int use_viewdirs,
                              int output_ch, int input_mode, const float* in0, const float* in1,

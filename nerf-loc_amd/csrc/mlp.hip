@@ -221,19 +221,19 @@ void mlp_f32_kernel(MlpArgs a) {
     const int h = lane >> 5, c = lane & 31;
 
     const bool feat_mode = a.mode == NERF_IN_FEATURES;
-    const unsigned Mu = (unsigned)a.M;
+    // the samples of the network this workgroup serves: tile t covers s0 + 128 t ..., the last tile may be partial
+    const unsigned s0 = (unsigned)tw.sample0, Mu = (unsigned)tw.sample_end;
     RawIn nxt;
     if (!feat_mode && tw.first < tw.end) {
-        const unsigned m0 = (unsigned)(tw.base + tw.first) * 128u + wave * 32 + c;
+        const unsigned m0 = s0 + (unsigned)tw.first * 128u + wave * 32 + c;
         fetch_raw<VD>(a, m0 < Mu ? m0 : Mu - 1, nxt);
     }
 
     for (long long t = tw.first; t < tw.end; t += tw.stride) {
-        const long long tile = tw.base + t;
-        const unsigned m = (unsigned)tile * 128u + wave * 32 + c;
+        const unsigned m = s0 + (unsigned)t * 128u + wave * 32 + c;
         const RawIn cur = nxt;
         if (!feat_mode && t + tw.stride < tw.end) {
-            const unsigned mn = (unsigned)(tile + tw.stride) * 128u + wave * 32 + c;
+            const unsigned mn = s0 + (unsigned)(t + tw.stride) * 128u + wave * 32 + c;
             fetch_raw<VD>(a, mn < Mu ? mn : Mu - 1, nxt);
         }
         float pe[32], vw[16];
@@ -736,9 +736,7 @@ static int mlp_forward_impl(const char* who, const void* packed, const void* con
     if (table) {
         NERF_REQUIRE(n_objects >= 1 && R % n_objects == 0, "%s: %d rays do not split evenly over %d networks", who, R, n_objects);
         const long long per_obj = M / n_objects;
-        // the float32 kernel walks whole tiles; the bf16 kernel bounds every network's last tile by its sample count
-        if (precision != NERF_PREC_BF16)
-            NERF_REQUIRE(per_obj % per_tile == 0, "%s: samples per network (%lld) must be a multiple of %d", who, per_obj, per_tile);
+        // both kernels bound every network's last tile by its sample count
         NERF_REQUIRE(n_objects <= cu_count(), "%s: at most %d networks per launch, got %d", who, cu_count(), n_objects);
         a.table = reinterpret_cast<const unsigned char* const*>(table);
         a.n_obj = n_objects;

@@ -47,8 +47,7 @@ def _fusable(fn, embed_fn, embeddirs_fn, has_viewdirs):
 
 
 def _query_objects(nets, query_fn, rays, z, has_vd):
-    """Several networks, each evaluating its equal share of the ray batch: one launch (nerf_mlp_forward_objects); the
-    float32 kernel needs the shares to line up with its 128-sample tiles, else one launch per network on its slice."""
+    """Several networks, each evaluating its equal share of the ray batch: one launch (nerf_mlp_forward_objects)."""
     n, N_rays, S, cols = len(nets), rays.shape[0], z.shape[1], rays.shape[1]
     first = nets[0]
     if N_rays % n:
@@ -60,14 +59,11 @@ def _query_objects(nets, query_fn, rays, z, has_vd):
                                                                           first.precision_code()):
             raise ValueError("the networks of a batch must share architecture and precision")
     prec = first.precision_code()
-    per = N_rays // n
-    if N_rays and (prec == hip.PREC_BF16 or (per * S) % 128 == 0):
+    if N_rays:
         out = hip.mlp_forward_objects([net.packed_weights(prec) for net in nets], prec, first.use_viewdirs,
                                       first.out_channels, hip.IN_RAYS, rays, z, N_rays, S, cols)
     else:
-        out = torch.cat([hip.mlp_forward(net.packed_weights(prec), prec, net.use_viewdirs, net.out_channels, hip.IN_RAYS,
-                                         rays[i * per:(i + 1) * per], z[i * per:(i + 1) * per], per, S, cols)
-                         for i, net in enumerate(nets)], 0)
+        out = torch.empty((0, first.out_channels), dtype=torch.float32, device=rays.device)
     return out.reshape(N_rays, S, first.out_channels)
 
 

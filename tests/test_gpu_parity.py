@@ -800,9 +800,8 @@ def test_invalid_arguments_raise(dev):
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_object_batch_equals_per_object_renders(dev, precision):
     """Three objects, each with its own network, rendered as one batch (nerf_mlp_forward_objects: one network launch)
-    against three separate renders: bit for bit, in both precisions; shares that do not fill the kernel's tiles (320
-    samples in bf16 mode, where a network's last tile may be partial; 128 in float32 mode, where such shares take the
-    per-object path) give the same."""
+    against three separate renders: bit for bit, in both precisions, also for shares that do not fill the kernel's
+    tiles (320 samples in bf16 mode, 128 in float32 mode: a network's last tile may be partial in both)."""
     import types
     from nerf_loc_amd import nerf_utils
     args = types.SimpleNamespace(nerf_render_rgb=True, nerf_render_depth=True)
@@ -817,7 +816,13 @@ def test_object_batch_equals_per_object_renders(dev, precision):
         K = np.array([[14.0, 0, 0.5 * W], [0, 14.0, 0.5 * H], [0, 0, 1]])
         poses = [[T(synth.pose_spherical(40.0 * o + 25.0 * i, -25.0, 1.6)[:3, :4].astype(F32), dev) for i in range(P)]
                  for o in range(3)]
-        rgbs, disps, raws, depths = nerf_utils.render_path_device_objects(poses, [H, W, 14.0], K, kws)
+        from nerf_loc_amd import hip
+        hip.MLP_EVENTS = []
+        try:
+            rgbs, disps, raws, depths = nerf_utils.render_path_device_objects(poses, [H, W, 14.0], K, kws)
+            assert len(hip.MLP_EVENTS) == 1                        # one network launch for the three objects
+        finally:
+            hip.MLP_EVENTS = None
         assert tuple(raws.shape) == (3, P, H, W, 64, 4) and tuple(rgbs.shape) == (3, P, H, W, 3)
         for o in range(3):
             r1, d1, w1, z1 = nerf_utils.render_path_device(poses[o], [H, W, 14.0], K, kws[o])
