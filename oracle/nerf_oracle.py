@@ -483,6 +483,35 @@ def render_image(H, W, K, c2w, sd_coarse, near, far, use_viewdirs=True, ndc=Fals
     return {k: v.reshape((H, W) + v.shape[1:]) for k, v in r.items()}
 
 
+def detector_assembly(input_type, rgbs, raws, depths, fine_depths=None):
+    """The tensor Model3DETR.forward hands to its backbone for one field of view, from render_path's numpy outputs
+    rgbs [P,H,W,3], raws [P,H,W,S,4], depths [P,H,W] (models/model_3detr.py:657-670 for the fine field of view,
+    :699-712 for the coarse one).  For the depth input types NaN depths are set to 1 first (:644-647, :686-690).
+    fine_depths: the reference builds the coarse 'rendered_depth' tensor from the FINE depths (:702); pass them to
+    reproduce that.  Restated from the source: the method cannot be run here (the detector needs its CUDA point-cloud
+    extension), so this part of the checker is not pinned by fixtures."""
+    if input_type in ("rendered_depth", "nerf_rendered_depth", "nerf_rendered_rgb_rendered_depth",
+                      "rendered_rgb_rendered_depth"):
+        depths = np.nan_to_num(depths, nan=1.0)
+        if fine_depths is not None:
+            fine_depths = np.nan_to_num(fine_depths, nan=1.0)
+    rgb4 = np.repeat(rgbs[..., None], 4, axis=-1)
+    dep4 = np.repeat(depths[..., None, None], 4, axis=-1)
+    if input_type == "rendered_rgb":
+        return rgbs
+    if input_type == "rendered_depth":
+        return (depths if fine_depths is None else fine_depths)[..., None]
+    if input_type == "nerf_rendered_rgb":
+        return np.concatenate((raws, rgb4), axis=-2)
+    if input_type == "nerf_rendered_depth":
+        return np.concatenate((raws, dep4), axis=-2)
+    if input_type == "nerf_rendered_rgb_rendered_depth":
+        return np.concatenate((raws, rgb4, dep4), axis=-2)
+    if input_type == "rendered_rgb_rendered_depth":
+        return np.concatenate((rgb4, dep4), axis=-2)
+    return raws
+
+
 def img2mse(x, y):
     return np.mean((x - y) ** 2, dtype=np.float64)
 
