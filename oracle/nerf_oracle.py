@@ -9,7 +9,10 @@ of bench.py.  The product package never imports it.
 Parity status: PINNED.  tests/test_oracle_golden.py checks every function here
 against tests/golden/*.npz, which were produced by running the reference on CPU
 (tests/golden/make_golden.py): deterministic sample_pdf indices and samples
-bit-exact, everything else to <= 2e-6.
+bit-exact, everything else to <= 2e-6.  Two functions have no fixture behind
+them and say so in their docstrings: detector_assembly (the reference method
+it restates cannot be run without the detector's CUDA extension) and the bf16
+variant of mlp_backward (the reference has no such mode).
 
 Arithmetic notes (they matter for bit-exact sample_pdf):
   * torch.sum over a contiguous float32 row on CPU is an 8-lane, 4-accumulator
