@@ -20,6 +20,11 @@ if [ "$part" = a ]; then
     timeout -k 10 200 python bench.py --workload $w --no-cpu-baseline --no-extras --steps 3 --warmup 1 > "$out/bench_$w.json"
   done
   timeout -k 10 200 python bench.py --workload train --train-precision bf16 --no-cpu-baseline --no-extras --steps 10 --warmup 3 > "$out/bench_train_bf16.json"
+  timeout -k 10 200 python bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-extras > "$out/bench_sustained_200.json"
+  cp "$out/bench_sustained_200.json" profiles/${tag}_bench_sustained_200.json
+  NERF_DIST_BACKEND=gloo timeout -k 10 500 python bench.py --gpus 8 --steps 2 --warmup 1 > "$out/eight_rank_rehearsal.txt"
+  tail -1 "$out/eight_rank_rehearsal.txt" > profiles/${tag}_eight_rank_rehearsal.txt
+  timeout -k 10 250 python3 tools/c_abi/bench_graph.py > profiles/${tag}_c_abi_graph.txt
   for p in bf16 fp32; do cp "$out/bench_$p.json" profiles/${tag}_bench_$p.json; done
   for w in rays4m objects train train_bf16; do cp "$out/bench_$w.json" profiles/${tag}_bench_$w.json; done
   cp "$out/gpu_tests.log" profiles/${tag}_gpu_tests.log
