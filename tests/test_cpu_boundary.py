@@ -298,3 +298,12 @@ def test_ray_bank_batching_mode_follows_the_reference_draws():
     torch.manual_seed(3)
     perm = torch.randperm(90)
     assert np.array_equal(bank.rays_rgb.numpy(), ref[perm.numpy()])
+
+
+def test_c_program_is_built_and_links_the_library():
+    """nerf-loc_amd/lib/render_c (tools/c_abi/render_c.cpp) is built with the library; without arguments it prints its
+    usage and touches no GPU."""
+    binary = os.path.join(ROOT, "nerf-loc_amd", "lib", "render_c")
+    assert os.path.exists(binary), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    p = subprocess.run([binary], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "usage: render_c" in p.stderr
