@@ -528,7 +528,7 @@ def g14():
     rs = np.random.RandomState(1414)
     out = {}
     for nb, ns in G14_PDF_SHAPES:
-        R = 24
+        R = 16
         bins, w = pdf_inputs(rs, R, nb)
         tag = "p%d_%d" % (nb, ns)
         out[tag + "_bins"], out[tag + "_weights"] = bins, w
@@ -538,10 +538,10 @@ def g14():
             out["%s_%s_samples" % (tag, mode)] = n(smp)
             out["%s_%s_inds" % (tag, mode)] = n(rec.out[0]).astype(np.int16)
     for S in G14_COMPOSITE_S:
-        R = 16
+        R = 8
         raw = rs.normal(size=(R, S, 4)).astype(np.float32)
-        raw[8:] *= np.float32(20.0)
-        raw[14:, :, 3] = -np.abs(raw[14:, :, 3])
+        raw[4:] *= np.float32(20.0)
+        raw[7:, :, 3] = -np.abs(raw[7:, :, 3])
         z = np.sort(rs.uniform(0.1, 9.0, size=(R, S)), -1).astype(np.float32)
         d = (rs.normal(size=(R, 3)) * rs.uniform(0.5, 2.0, size=(R, 1))).astype(np.float32)
         out["c%d_raw" % S], out["c%d_z" % S], out["c%d_d" % S] = raw, z, d
