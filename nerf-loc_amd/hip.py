@@ -124,6 +124,19 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _dir_ptr(d, dev, R, d_stride):
+    """Pointer to the first direction component of ray 0: `d` may be a strided view into the ray batch (rays[:, 3:6]),
+    so it is checked here instead of being made contiguous."""
+    if not isinstance(d, torch.Tensor) or not d.is_cuda or d.device != dev:
+        raise ValueError("rays_d must live on %s (got %s); this engine has no CPU path"
+                         % (dev, d.device if isinstance(d, torch.Tensor) else type(d).__name__))
+    if d.dtype != torch.float32 or d.dim() != 2 or d.shape[0] != R or d.shape[1] < 3 or (R > 1 and d.stride(0) != d_stride) \
+            or d.stride(1) != 1:
+        raise ValueError("rays_d must be a float32 [%d, 3] view with unit inner stride and row stride %d, got %s %s strides %s"
+                         % (R, d_stride, d.dtype, tuple(d.shape), tuple(d.stride())))
+    return ctypes.c_void_p(d.data_ptr())
+
+
 def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -327,7 +340,7 @@ def raw2outputs(raw, z, d, d_stride, noise=None, white_bkgd=False, want_weights=
     # one sample per ray: the reference's interval list is empty and so are its weights (run_nerf.py:283-284)
     weights = torch.empty((R, S if S > 1 else 0), **f) if want_weights else None
     with torch.cuda.device(dev):
-        _check(lib().nerf_raw2outputs(_ptr(raw), ch, _ptr(z), ctypes.c_void_p(d.data_ptr()), int(d_stride),
+        _check(lib().nerf_raw2outputs(_ptr(raw), ch, _ptr(z), _dir_ptr(d, dev, R, int(d_stride)), int(d_stride),
                                       _ptr(noise), R, S, int(bool(white_bkgd)), _ptr(rgb), _ptr(disp), _ptr(acc),
                                       _ptr(depth), _ptr(weights), _stream(raw)), "nerf_raw2outputs")
     return rgb, disp, acc, weights, depth
@@ -383,7 +396,7 @@ def raw2outputs_backward(raw, z, d, d_stride, noise, white_bkgd, g_rgb=None, g_d
     noise = _f32(noise, "noise", dev) if noise is not None else None
     d_raw = torch.empty_like(raw)
     with torch.cuda.device(dev):
-        _check(lib().nerf_raw2outputs_backward(_ptr(raw), ch, _ptr(z), ctypes.c_void_p(d.data_ptr()), int(d_stride),
+        _check(lib().nerf_raw2outputs_backward(_ptr(raw), ch, _ptr(z), _dir_ptr(d, dev, R, int(d_stride)), int(d_stride),
                                                _ptr(noise), R, S, int(bool(white_bkgd)), _ptr(gs[0]), _ptr(gs[1]),
                                                _ptr(gs[2]), _ptr(gs[3]), _ptr(d_raw), _stream(raw)),
                "nerf_raw2outputs_backward")

@@ -794,6 +794,15 @@ def test_invalid_arguments_raise(dev):
                         torch.zeros(8, 4, device=dev), 8, 4, 8)          # view directions missing from the ray rows
     with pytest.raises(ValueError):
         hip.z_vals(rays.double(), 8)
+    # ray directions are passed as a strided view, never copied: a host tensor, a short batch or a wrong stride must
+    # be refused before a kernel gets the pointer
+    raw, z = torch.zeros(8, 4, 4, device=dev), torch.zeros(8, 4, device=dev)
+    for bad in (rays[:, 3:6].cpu(), rays[:4, 3:6], rays[:, 3:6].double(), rays[:, 3:6].t().contiguous().t()):
+        with pytest.raises(ValueError):
+            hip.raw2outputs(raw, z, bad, 11)
+    with pytest.raises(ValueError):
+        render.raw2outputs(raw, z, rays[:, 3:6].cpu())
+    assert hip.raw2outputs(raw, z, rays[:, 3:6], 11)[0].shape == (8, 3)
 
 
 # ------------------------------------------------------------------ several networks in one launch
