@@ -137,6 +137,27 @@ def _dir_ptr(d, dev, R, d_stride):
     return ctypes.c_void_p(d.data_ptr())
 
 
+def _need(cond, msg, *args):
+    """Operand sizes are checked here, before a kernel is launched on them: an out-of-bounds access on the GPU is not
+    an exception but a fault that can take the device down."""
+    if not cond:
+        raise ValueError(msg % args)
+
+
+def _mlp_operands_ok(who, mode, use_viewdirs, in0, in1, R, S, ray_cols):
+    R, S = int(R), int(S)
+    _need(R >= 0 and S >= 1, "%s: bad shape R=%d S=%d", who, R, S)
+    if mode == IN_RAYS:
+        _need(in1 is not None and in0.numel() >= R * int(ray_cols) and in1.numel() >= R * S,
+              "%s: rays need %d x %d and z_vals %d x %d elements", who, R, int(ray_cols), R, S)
+    elif mode == IN_POINTS:
+        _need(in0.numel() >= R * S * 3 and (in1 is None or in1.numel() >= R * 3),
+              "%s: points need %d x 3 and view directions %d x 3 elements", who, R * S, R)
+    else:
+        ch = 90 if use_viewdirs else 63
+        _need(in0.numel() >= R * S * ch, "%s: features need %d x %d elements", who, R * S, ch)
+
+
 def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -178,7 +199,12 @@ def make_rays(H, W, K, c2w=None, rays_o=None, rays_d=None, near=0.0, far=1.0, us
         o_in, d_in = _f32(rays_o.reshape(-1, 3), "rays_o"), _f32(rays_d.reshape(-1, 3), "rays_d")
         dev = d_in.device
         n = d_in.shape[0]
+        _need(o_in.shape[0] == n and o_in.device == dev, "make_rays: %d origins on %s for %d directions on %s",
+              o_in.shape[0], o_in.device, n, dev)
         cv = None
+    for name, arr in (("near", near_arr), ("far", far_arr)):
+        _need(arr is None or (arr.numel() == n and arr.device == dev), "make_rays: per-ray %s must hold %d values on %s",
+              name, n, dev)
     out = torch.empty((n, 11 if use_viewdirs else 8), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _check(lib().nerf_make_rays(n, int(H), int(W), _ptr(o_in), _ptr(d_in), _ptr(c2w) if rays_o is None else None,
@@ -221,6 +247,8 @@ def z_vals(rays, n_samples, lindisp=False, t_rand=None, t_vals=None):
     R, cols = rays.shape
     tv = _f32(t_vals, "t_vals", rays.device) if t_vals is not None else linspace01(n_samples, rays.device)
     tr = _f32(t_rand, "t_rand", rays.device) if t_rand is not None else None
+    _need(rays.dim() == 2 and cols >= 8 and tv.numel() >= int(n_samples) >= 1,
+          "z_vals: rays must be [R, >= 8] and t_vals hold %d values", int(n_samples))
     if tr is not None and tuple(tr.shape) != (R, n_samples):
         raise ValueError("t_rand must be [%d, %d], got %s" % (R, n_samples, tuple(tr.shape)))
     out = torch.empty((R, n_samples), dtype=torch.float32, device=rays.device)
@@ -282,6 +310,7 @@ MLP_EVENTS = None
 def mlp_forward(packed, precision, use_viewdirs, output_ch, mode, in0, in1, R, S, ray_cols=0):
     in0 = _f32(in0, "mlp input")
     in1 = _f32(in1, "mlp second input", in0.device) if in1 is not None else None
+    _mlp_operands_ok("mlp_forward", mode, use_viewdirs, in0, in1, R, S, ray_cols)
     out = torch.empty((R * S, output_ch), dtype=torch.float32, device=in0.device)
     ev = MLP_EVENTS
     with torch.cuda.device(in0.device):
@@ -303,6 +332,8 @@ def mlp_forward_objects(packed_list, precision, use_viewdirs, output_ch, mode, i
     in0 = _f32(in0, "mlp input")
     in1 = _f32(in1, "mlp second input", in0.device) if in1 is not None else None
     n = len(packed_list)
+    _mlp_operands_ok("mlp_forward_objects", mode, use_viewdirs, in0, in1, R, S, ray_cols)
+    _need(all(p.is_cuda and p.device == in0.device for p in packed_list), "mlp_forward_objects: packed networks on another device")
     table = torch.tensor([p.data_ptr() for p in packed_list], dtype=torch.int64).to(in0.device)
     out = torch.empty((R * S, output_ch), dtype=torch.float32, device=in0.device)
     ev = MLP_EVENTS
@@ -332,6 +363,7 @@ def raw2outputs(raw, z, d, d_stride, noise=None, white_bkgd=False, want_weights=
         raise ValueError("z_vals %s does not match raw %s" % (tuple(z.shape), tuple(raw.shape)))
     dev = raw.device
     noise = _f32(noise, "noise", dev) if noise is not None else None
+    _need(noise is None or noise.numel() == R * S, "raw2outputs: noise must hold %d x %d values", R, S)
     f = dict(dtype=torch.float32, device=dev)
     rgb = torch.empty((R, 3), **f) if want_rgb else None
     acc = torch.empty((R,), **f)
@@ -375,6 +407,7 @@ def sample_pdf(bins, weights, u, bins_are_z=False, z_vals=None, want_samples=Tru
     zsorted = None
     if want_sorted:
         z_vals = _f32(z_vals, "z_vals", dev)
+        _need(z_vals.dim() == 2 and z_vals.shape[0] == R, "sample_pdf: z_vals must be [%d, n]", R)
         n_z = z_vals.shape[1]
         zsorted = torch.empty((R, n_z + n_u), **f)
     std = torch.empty((R,), **f) if want_std else None
@@ -392,8 +425,13 @@ def raw2outputs_backward(raw, z, d, d_stride, noise, white_bkgd, g_rgb=None, g_d
     raw, z = _f32(raw, "raw"), _f32(z, "z_vals", raw.device)
     R, S, ch = raw.shape
     dev = raw.device
+    _need(tuple(z.shape) == (R, S), "raw2outputs_backward: z_vals %s does not match raw %s", tuple(z.shape), tuple(raw.shape))
     gs = [None if g is None else _f32(g, "upstream gradient", dev) for g in (g_rgb, g_disp, g_acc, g_depth)]
+    for g, n_el in zip(gs, (3 * R, R, R, R)):
+        _need(g is None or g.numel() == n_el, "raw2outputs_backward: an upstream gradient holds %d values, %d expected",
+              0 if g is None else g.numel(), n_el)
     noise = _f32(noise, "noise", dev) if noise is not None else None
+    _need(noise is None or noise.numel() == R * S, "raw2outputs_backward: noise must hold %d x %d values", R, S)
     d_raw = torch.empty_like(raw)
     with torch.cuda.device(dev):
         _check(lib().nerf_raw2outputs_backward(_ptr(raw), ch, _ptr(z), _dir_ptr(d, dev, R, int(d_stride)), int(d_stride),
@@ -425,6 +463,7 @@ def mlp_forward_train(packed, use_viewdirs, output_ch, mode, in0, in1, R, S, ray
     in1 = _f32(in1, "mlp second input", in0.device) if in1 is not None else None
     M = R * S
     vd = int(bool(use_viewdirs))
+    _mlp_operands_ok("mlp_forward_train", mode, use_viewdirs, in0, in1, R, S, ray_cols)
     out = torch.empty((M, output_ch), dtype=torch.float32, device=in0.device)
     tape = torch.empty((lib().nerf_train_tape_bytes(M, vd, prec) // 4,), dtype=torch.float32, device=in0.device)
     with torch.cuda.device(in0.device):
@@ -449,6 +488,8 @@ def mlp_backward(packed_bwd, use_viewdirs, output_ch, d_raw, tape, shapes, preci
     vd = int(bool(use_viewdirs))
     if M == 0:      # an empty shard of a data-parallel batch: zero gradients, so the all-reduce still lines up
         return [None if s is None else torch.zeros(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    _need(tape.is_cuda and tape.device == dev and tape.numel() * tape.element_size() >= lib().nerf_train_tape_bytes(M, vd, prec),
+          "mlp_backward: the tape does not belong to a forward of %d samples on %s", M, dev)
     gtape = torch.empty((lib().nerf_train_grad_tape_bytes(M, vd, prec) // 4,), dtype=torch.float32, device=dev)
     ws = _WORKSPACE.get(str(dev))
     if ws is None:
@@ -475,6 +516,12 @@ def mlp_backward_static(packed_bwd, use_viewdirs, output_ch, d_raw, tape, grads,
     prec = PRECISIONS[precision]
     d_raw = _f32(d_raw, "d_raw")
     M = d_raw.numel() // output_ch
+    vd = int(bool(use_viewdirs))
+    _need(tape.is_cuda and tape.device == d_raw.device and
+          tape.numel() * tape.element_size() >= lib().nerf_train_tape_bytes(max(M, 1), vd, prec),
+          "mlp_backward_static: the tape does not belong to a forward of %d samples on %s", M, d_raw.device)
+    _need(all(g is None or (g.is_cuda and g.device == d_raw.device and g.dtype == torch.float32 and g.is_contiguous())
+              for g in grads), "mlp_backward_static: gradient tensors must be contiguous float32 on %s", d_raw.device)
     arr = (ctypes.c_void_p * len(grads))(*[None if g is None else g.data_ptr() for g in grads])
     with torch.cuda.device(d_raw.device):
         _check(lib().nerf_mlp_backward_static(ctypes.c_void_p(packed_bwd.data_ptr()),
@@ -492,8 +539,10 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps,
         sl = slice(i, min(n, i + 64))
         ps, gs, ms, vs = params[sl], grads[sl], exp_avgs[sl], exp_avg_sqs[sl]
         for t in ps + gs + ms + vs:
-            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-                raise ValueError("adam_step needs contiguous float32 GPU tensors")
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == ps[0].device):
+                raise ValueError("adam_step needs contiguous float32 tensors on one GPU")
+        for p_, g_, m_, v_ in zip(ps, gs, ms, vs):
+            _need(g_.numel() == p_.numel() == m_.numel() == v_.numel(), "adam_step: gradient / moment sizes differ from the parameter's")
         k = len(ps)
         mk = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
         numel = (ctypes.c_longlong * k)(*[t.numel() for t in ps])

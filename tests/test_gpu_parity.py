@@ -803,6 +803,25 @@ def test_invalid_arguments_raise(dev):
     with pytest.raises(ValueError):
         render.raw2outputs(raw, z, rays[:, 3:6].cpu())
     assert hip.raw2outputs(raw, z, rays[:, 3:6], 11)[0].shape == (8, 3)
+    # operand sizes that do not cover what the kernel would read
+    with pytest.raises(ValueError):
+        hip.mlp_forward(net.packed_weights(0), 0, True, 4, hip.IN_RAYS, rays, torch.zeros(8, 3, device=dev), 8, 4, 11)
+    with pytest.raises(ValueError):
+        hip.mlp_forward(net.packed_weights(0), 0, True, 4, hip.IN_POINTS, torch.zeros(8 * 4 - 1, 3, device=dev),
+                        rays[:, 8:11].contiguous(), 8, 4)
+    with pytest.raises(ValueError):
+        hip.mlp_forward(net.packed_weights(0), 0, True, 4, hip.IN_FEATURES, torch.zeros(8, 63, device=dev), None, 8, 1)
+    with pytest.raises(ValueError):
+        hip.raw2outputs(raw, z, rays[:, 3:6], 11, noise=torch.zeros(8, 3, device=dev))
+    with pytest.raises(ValueError):
+        hip.make_rays(2, 4, np.eye(3), rays_o=rays[:, :3], rays_d=rays[:, 3:6], near=torch.zeros(5, device=dev))
+    with pytest.raises(ValueError):
+        hip.make_rays(2, 4, np.eye(3), rays_o=rays[:4, :3], rays_d=rays[:, 3:6])
+    with pytest.raises(ValueError):
+        hip.z_vals(rays, 8, t_vals=torch.zeros(4, device=dev))
+    with pytest.raises(ValueError):
+        hip.sample_pdf(torch.zeros(4, 9, device=dev), torch.zeros(4, 7, device=dev), hip.linspace01(4, dev), bins_are_z=True,
+                       z_vals=torch.zeros(3, 9, device=dev), want_sorted=True)
 
 
 # ------------------------------------------------------------------ several networks in one launch
