@@ -201,15 +201,17 @@ def mlp_forward(sd, feat, use_viewdirs=True, D=8, skips=(4,), input_ch=63):
     return np.concatenate([rgb, alpha], -1)
 
 
-def run_network(sd, pts, viewdirs, use_viewdirs=True, chunk=1 << 16):
-    """pts [R,S,3] (+ viewdirs [R,3]) -> raw [R,S,C].  run_nerf.py:37-51."""
+def run_network(sd, pts, viewdirs, use_viewdirs=True, chunk=1 << 16, mlp=None):
+    """pts [R,S,3] (+ viewdirs [R,3]) -> raw [R,S,C].  run_nerf.py:37-51.  mlp: the network evaluation to use on the
+    encoded features, (sd, features, use_viewdirs) -> raw; default mlp_forward."""
+    mlp = mlp or mlp_forward
     R, S = pts.shape[:2]
     flat = pts.reshape(-1, 3)
     f = embed(flat, 10)
     if use_viewdirs:
         vd = np.broadcast_to(viewdirs[:, None, :], pts.shape).reshape(-1, 3)
         f = np.concatenate([f, embed(vd, 4)], -1)
-    outs = [mlp_forward(sd, f[i:i + chunk], use_viewdirs) for i in range(0, f.shape[0], chunk)]
+    outs = [mlp(sd, f[i:i + chunk], use_viewdirs) for i in range(0, f.shape[0], chunk)]
     out = np.concatenate(outs, 0)
     return out.reshape(R, S, out.shape[-1])
 
@@ -300,7 +302,7 @@ def z_vals_for(rays, N_samples, lindisp=False, t_rand=None):
 
 def render_rays(rays, sd_coarse, N_samples, N_importance=0, sd_fine=None, use_viewdirs=True,
                 white_bkgd=False, lindisp=False, t_rand=None, u=None, noise0=None, noise1=None,
-                retraw=False, z_samples_override=None):
+                retraw=False, z_samples_override=None, mlp=None):
     """Coarse (and optionally fine) pass over a [R, 8|11] ray batch.
 
     t_rand [R,S]: stratified jitter (None = perturb 0); u [R,N_imp] or [N_imp]:
@@ -308,7 +310,7 @@ def render_rays(rays, sd_coarse, N_samples, N_importance=0, sd_fine=None, use_vi
     density noise of the two passes; z_samples_override [R,N_imp]: importance
     samples to use for the fine pass instead of the ones computed here (lets a
     test compare the fine pass on identical sample positions, since positions
-    inside empty bins are ill-conditioned).  Keys of the result follow
+    inside empty bins are ill-conditioned); mlp: see run_network.  Keys of the result follow
     run_nerf.py:409-418 plus depth_map (nerf_utils.py:330), weights and z_vals.
     """
     dt = rays.dtype.type
@@ -318,7 +320,7 @@ def render_rays(rays, sd_coarse, N_samples, N_importance=0, sd_fine=None, use_vi
         raise ValueError("use_viewdirs needs an 11-column ray batch")
     z = z_vals_for(rays, N_samples, lindisp, t_rand)
     pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
-    raw = run_network(sd_coarse, pts, vd, use_viewdirs)
+    raw = run_network(sd_coarse, pts, vd, use_viewdirs, mlp=mlp)
     rgb, disp, acc, w, depth = raw2outputs(raw, z, d, noise0, white_bkgd)
     ret = {}
     if N_importance > 0:
@@ -334,7 +336,7 @@ def render_rays(rays, sd_coarse, N_samples, N_importance=0, sd_fine=None, use_vi
             zs = z_samples_override.astype(rays.dtype)
         z = np.sort(np.concatenate([z, zs], -1), -1)
         pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
-        raw = run_network(sd_fine if sd_fine is not None else sd_coarse, pts, vd, use_viewdirs)
+        raw = run_network(sd_fine if sd_fine is not None else sd_coarse, pts, vd, use_viewdirs, mlp=mlp)
         rgb, disp, acc, w, depth = raw2outputs(raw, z, d, noise1, white_bkgd)
         ret.update(z_samples=zs, inds=inds,
                    z_std=np.sqrt(((zs.astype(np.float64) - zs.astype(np.float64).mean(-1, keepdims=True)) ** 2)
@@ -394,6 +396,60 @@ def bf16_round(x):
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
     r = ((u >> 16) & 1) + np.uint32(0x7FFF)
     return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32).astype(np.float64)
+
+
+def bf16_split(x, terms):
+    """x as a sum of `terms` bfloat16 numbers, leading term first: t0 = bf16(x), t1 = bf16(x - t0), ...  (every
+    difference is exact in float32).  Returned as float64 arrays; one term is plain rounding."""
+    x = np.asarray(x, dtype=np.float32)
+    out, rest = [], x
+    for _ in range(terms):
+        t = bf16_round(rest)
+        out.append(t)
+        rest = (rest.astype(np.float64) - t).astype(np.float32)
+    return out
+
+
+def _split_product(x_terms, w_terms):
+    """sum over the term pairs (i, j) with i + j < number of terms of x_i @ w_j^T: one product for plain bf16, three
+    for two terms, six for three.  The dropped pairs are below 2^-8 terms of the leading product."""
+    n = len(x_terms)
+    acc = 0.0
+    for i in range(n):
+        for j in range(n - i):
+            acc = acc + x_terms[i] @ w_terms[j].T
+    return acc
+
+
+def mlp_forward_bf16(sd, feat, use_viewdirs=True, terms=1, layer_terms=None):
+    """NeRF.forward (run_nerf_helpers.py:96-119) as the bf16 matrix-core kernels evaluate it: every matrix-product
+    operand (weight, encoded input, stored activation) is a sum of `terms` bfloat16 numbers, products are exact and
+    summed in higher precision, the bias joins the sum unrounded, and each layer's output is rounded to float32
+    before ReLU and the split into operands of the next layer.  terms=1 is the plain bf16 mode, terms=3 with its six
+    leading products per element the float32-accurate mode.  layer_terms: {layer name: terms} overrides per layer
+    (both operands of that layer's product).  The reference has no such mode: no fixture pins this function; it is the
+    yardstick that separates the format's error from a kernel's."""
+    lt = layer_terms or {}
+    f32 = lambda v: np.asarray(v, np.float64).astype(np.float32)
+
+    def lin(name, x32):
+        n = lt.get(name, terms)
+        y = _split_product(bf16_split(x32, n), bf16_split(sd[name + ".weight"], n)) + sd[name + ".bias"].astype(np.float64)
+        return f32(y)
+
+    feat = np.asarray(feat, np.float32)
+    pts, views = feat[:, :63], feat[:, 63:]
+    h = pts
+    for i in range(8):
+        h = np.maximum(lin("pts_linears.%d" % i, h), 0)
+        if i == 4:
+            h = np.concatenate([pts, h], -1)
+    if not use_viewdirs:
+        return lin("output_linear", h)
+    alpha = lin("alpha_linear", h)
+    feature = lin("feature_linear", h)
+    hv = np.maximum(lin("views_linears.0", np.concatenate([feature, views], -1)), 0)
+    return np.concatenate([lin("rgb_linear", hv), alpha], -1)
 
 
 def mlp_backward(sd, feat, d_raw, use_viewdirs=True, bf16=False):

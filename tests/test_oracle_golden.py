@@ -459,3 +459,38 @@ def test_bf16_restatement_of_the_network_backward():
     for k in g64:
         rel = np.linalg.norm(g16[k] - g64[k]) / np.linalg.norm(g64[k])
         assert rel < (0.02 if k.startswith(("rgb", "alpha")) else 0.25), (k, rel)
+
+
+# ------------------------------------------------------------------ reduced-precision restatements
+def test_bf16_split_is_exact_and_ordered():
+    """bf16_split: the terms are bfloat16 numbers, each at most 2^-8 of the one before, and three of them reproduce a
+    float32 exactly (24 significant bits = 3 x 8)."""
+    rs = np.random.RandomState(3)
+    x = (rs.standard_normal(20000) * 10.0 ** rs.uniform(-6, 6, 20000)).astype(np.float32)
+    t = orc.bf16_split(x, 3)
+    for k in t:
+        assert np.array_equal(orc.bf16_round(k), k)
+    assert np.array_equal((t[0] + t[1] + t[2]).astype(np.float32), x)
+    nz = t[0] != 0
+    assert (np.abs(t[1][nz]) <= np.abs(t[0][nz]) * 2.0 ** -8).all()
+    assert (np.abs(t[2][nz]) <= np.abs(t[0][nz]) * 2.0 ** -16).all()
+    one = orc.bf16_split(x, 1)[0]
+    assert (np.abs(one - x) <= np.abs(x) * 2.0 ** -8).all()
+
+
+def test_mlp_forward_bf16_limits(golden):
+    """mlp_forward_bf16 against the pinned float32 network on the reference's own inputs (g4): three terms per operand
+    (six products per element) agree with float32 to its rounding, two terms to 2^-16, one term (plain bf16) to 2^-8
+    of the output scale; each step is an improvement of two orders of magnitude."""
+    g = golden("g4_mlp")
+    feat = g["feat"][:1024]
+    for regime in "AB":
+        sd = synth.make_state_dict(40, regime)
+        ref = g["out_vd_" + regime][:1024]
+        scale = np.abs(ref).max()
+        e = [np.abs(orc.mlp_forward_bf16(sd, feat, terms=n) - ref).max() / scale for n in (1, 2, 3)]
+        print("regime %s: max error / scale with 1, 2, 3 bf16 terms: %.2e %.2e %.2e" % (regime, *e))
+        assert e[2] < 2e-6 and e[1] < 1e-4 and e[0] < 2e-2
+        assert e[0] > 30 * e[1] and e[1] > 10 * e[2]
+        mixed = orc.mlp_forward_bf16(sd, feat, terms=1, layer_terms={"alpha_linear": 3})
+        assert np.abs(mixed[:, :3] - orc.mlp_forward_bf16(sd, feat, terms=1)[:, :3]).max() == 0    # colour branch untouched
