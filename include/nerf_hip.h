@@ -34,6 +34,10 @@ extern "C" {
 #define NERF_PREC_F32 0       /* exact float32 MFMA (v_mfma_f32_32x32x2_f32), fmaf-chain numerics */
 #define NERF_PREC_BF16 1      /* bf16 operands, float32 accumulation (v_mfma_f32_16x16x32_bf16 for   */
                               /* inference, v_mfma_f32_32x32x16_bf16 in the training kernels)        */
+#define NERF_PREC_BF16X3 2    /* float32 accuracy on the bf16 matrix cores: every operand a sum of   */
+                              /* three bf16 terms, the six leading products per element, float32    */
+                              /* accumulation (inference entry points only)                         */
+#define NERF_PREC_BF16X2 3    /* two bf16 terms, three products: operands good to 2^-16              */
 
 /* what nerf_mlp_forward reads as its input */
 #define NERF_IN_FEATURES 0    /* in0 = already encoded features [M, 63(+27)] (NeRF.forward)        */

@@ -20,6 +20,7 @@
 #include "mlp_bf16.h"
 #include "mlp16.h"
 #include "train_bf16.h"
+#include "mlp_split.h"
 
 namespace nerf {
 
@@ -658,6 +659,7 @@ static size_t stream16_offset(int use_viewdirs) {
 }
 
 extern "C" size_t nerf_mlp_packed_bytes(int precision, int use_viewdirs) {
+    if (split_terms(precision)) return split_packed_bytes(split_terms(precision), use_viewdirs != 0);
     if (precision != NERF_PREC_BF16 && precision != NERF_PREC_F32) return 0;
     if (precision == NERF_PREC_BF16)
         return stream16_offset(use_viewdirs) + (size_t)frag_total(NERF_PREC_BF16, use_viewdirs) * FRAG_BYTES +
@@ -669,11 +671,21 @@ extern "C" size_t nerf_mlp_packed_bytes(int precision, int use_viewdirs) {
 extern "C" int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs, int output_ch, int precision,
                              void* packed_out, void* stream) {
     NERF_REQUIRE(tensors_host && packed_out, "nerf_mlp_pack: null pointer");
-    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_F32, "nerf_mlp_pack: unknown precision %d", precision);
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_F32 || split_terms(precision),
+                 "nerf_mlp_pack: unknown precision %d", precision);
     if (use_viewdirs) NERF_REQUIRE(output_ch == 4, "nerf_mlp_pack: with view directions the output is [rgb, sigma] (4 channels)");
     else NERF_REQUIRE(output_ch == 4 || output_ch == 5, "nerf_mlp_pack: output_ch must be 4 or 5, got %d", output_ch);
     PackArgs a;
     a.net = make_net_desc(use_viewdirs != 0, output_ch);
+    if (const int terms = split_terms(precision)) {
+        const int n_t = use_viewdirs ? 24 : 20;
+        for (int i = 0; i < 24; ++i) a.t[i] = i < n_t ? tensors_host[i] : nullptr;
+        for (int i = 0; i < n_t; ++i)
+            if (use_viewdirs || (i != 16 && i != 17)) NERF_REQUIRE(a.t[i], "nerf_mlp_pack: tensor %d is null", i);
+        a.bf16 = 1; a.with_scales = 0; a.total_frags = a.padded_frags = split_padded_frags(terms, use_viewdirs != 0);
+        a.out = static_cast<unsigned char*>(packed_out);
+        return launch_pack_split(a, terms, use_viewdirs != 0, as_stream(stream));
+    }
     a.bf16 = precision == NERF_PREC_BF16;
     a.with_scales = a.bf16;
     a.total_frags = total_frags(a.net, a.bf16);
@@ -703,7 +715,8 @@ static int mlp_forward_impl(const char* who, const void* packed, const void* con
                             int use_viewdirs, int output_ch, int input_mode, const float* in0, const float* in1, int R,
                             int S, int ray_cols, float* raw_out, void* stream) {
     NERF_REQUIRE((packed || table) && (R == 0 || (in0 && raw_out)), "%s: null pointer", who);
-    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_F32, "%s: unknown precision %d", who, precision);
+    const int terms = split_terms(precision);
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_F32 || terms, "%s: unknown precision %d", who, precision);
     NERF_REQUIRE(R >= 0 && S >= 1, "%s: bad shape R=%d S=%d", who, R, S);
     if (use_viewdirs) NERF_REQUIRE(output_ch == 4, "%s: output_ch must be 4 with view directions", who);
     else NERF_REQUIRE(output_ch == 4 || output_ch == 5, "%s: output_ch must be 4 or 5", who);
@@ -722,10 +735,10 @@ static int mlp_forward_impl(const char* who, const void* packed, const void* con
     const long long M = (long long)R * S;
     if (M == 0) return NERF_OK;
     NERF_REQUIRE(M < (1ll << 31) - 512, "%s: at most 2^31 - 512 samples per launch, got %lld", who, M);
-    const int per_tile = precision == NERF_PREC_BF16 ? m16::TILE16 : 128;
+    const int per_tile = terms ? split_samples_per_tile() : (precision == NERF_PREC_BF16 ? m16::TILE16 : 128);
     MlpArgs a;
     a.packed = static_cast<const unsigned char*>(packed);
-    a.n_stages = frag_total(precision, use_viewdirs) / STAGE_FRAGS;
+    a.n_stages = (terms ? split_padded_frags(terms, use_viewdirs != 0) : frag_total(precision, use_viewdirs)) / STAGE_FRAGS;
     a.n_bias_tiles = use_viewdirs ? BIAS_TILES_VD : BIAS_TILES_NOVD;
     a.mode = input_mode; a.in0 = in0; a.in1 = in1; a.R = R; a.S = S; a.ray_cols = ray_cols; a.M = M; a.out = raw_out;
     set_sample_divisor(a);
@@ -746,6 +759,10 @@ static int mlp_forward_impl(const char* who, const void* packed, const void* con
         grid = a.tiles_per_obj * n_objects <= cu_count() ? a.tiles_per_obj * n_objects : cu_count();
     }
     hipStream_t st = as_stream(stream);
+    if (terms) {
+        a.n_bias_tiles = ((use_viewdirs ? BIAS_TILES16_VD : BIAS_TILES16_NOVD) * 16 + 31) / 32;    // in units of 32 floats
+        return launch_mlp_split(a, terms, use_viewdirs != 0, output_ch, (unsigned)grid, st);
+    }
     if (precision == NERF_PREC_BF16) {
         if (table) a.table_off = stream16_offset(use_viewdirs); else a.packed += stream16_offset(use_viewdirs);
         a.n_bias_tiles = ((use_viewdirs ? BIAS_TILES16_VD : BIAS_TILES16_NOVD) * 16 + 31) / 32;    // in units of 32 floats

@@ -1,0 +1,14 @@
+// Host interface of the split-precision network kernels (mlp_split.hip): NERF_PREC_BF16X3 / NERF_PREC_BF16X2.
+#pragma once
+#include "mlp_device.h"
+
+namespace nerf {
+
+int split_terms(int precision);                                   // 3, 2, or 0 for the other precisions
+int split_padded_frags(int terms, bool use_viewdirs);             // stream length in 1 KiB fragments (stage-aligned)
+size_t split_packed_bytes(int terms, bool use_viewdirs);          // stream + bias tiles
+int split_samples_per_tile();                                     // samples a workgroup takes per pass
+int launch_pack_split(const PackArgs& a, int terms, bool use_viewdirs, hipStream_t stream);
+int launch_mlp_split(const MlpArgs& a, int terms, bool use_viewdirs, int output_ch, unsigned grid, hipStream_t stream);
+
+}  // namespace nerf
