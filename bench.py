@@ -34,7 +34,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 1186816          # 2 x 593 408 MAC (run_nerf_helpers.py:67-119 shapes), bias/activation/PE not counted
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks of MI355X
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0, "bf16x2": 2500.0}   # dense MFMA peaks of MI355X
+# bf16 products the split-operand modes issue per algorithmic multiply-add (operands as sums of 3 / 2 bf16 terms)
+PRODUCTS = {"bf16": 1, "fp32": 1, "bf16x3": 6, "bf16x2": 3}
+DTYPE = {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3", "bf16x2": "bf16x2"}
+KERNEL = {"bf16": "mlp16_bf16_kernel", "fp32": "mlp_f32_kernel", "bf16x3": "mlp_split_kernel<3>", "bf16x2": "mlp_split_kernel<2>"}
 
 
 def build_scene(device, precision, res, regime="B"):
@@ -55,43 +59,44 @@ def build_scene(device, precision, res, regime="B"):
     return H, W, K, torch.from_numpy(c2w).to(device), kwargs
 
 
-def cpu_baseline(seconds_target=12.0):
-    """The numpy oracle (a port of the reference's CPU path, pinned to the reference by golden fixtures) on a
-    bounded sample of the same workload: the first rays of the same view, coarse + fine."""
+def cpu_baseline(full=True):
+    """The numpy oracle (a port of the reference's CPU path, pinned to the reference by golden fixtures) on the host
+    cores, on two bounded samples: a 32 768-ray batch of the headline view with 64 + 128 samples (`value`), and
+    BASELINE configs[0] exactly: the whole 400 x 400 view, 160 000 rays, coarse pass only, random-init weights.
+    full=False (quick runs) takes an eighth of each."""
     from nerf_loc_amd import synth
     from oracle import nerf_oracle as orc
     H, W, K, c2w, near, far = synth.lego_camera(800, theta=30.0)
     o, d = orc.get_rays(H, W, K, c2w)
     rays = orc.pack_rays(o, d, near, far, True)
     sc, sf = synth.make_state_dict(0, "B"), synth.make_state_dict(1, "B")
-    n = 1024
+    n2 = 32768 if full else 4096
+    first = (H // 2) * W                      # rows through the middle of the view: rays that hit the scene
     t0 = time.time()
-    orc.render_rays(rays[:n], sc, 64, 128, sd_fine=sf, white_bkgd=True)
-    dt = time.time() - t0
-    n2 = int(min(16384, max(n, n * seconds_target / max(dt, 1e-3))))
-    n2 -= n2 % 256
-    t0 = time.time()
-    orc.render_rays(rays[:n2], sc, 64, 128, sd_fine=sf, white_bkgd=True)
+    for i in range(0, n2, 8192):              # 8192-ray chunks bound the oracle's memory (the reference chunks at 32 768)
+        orc.render_rays(rays[first + i:first + i + 8192], sc, 64, 128, sd_fine=sf, white_bkgd=True)
     dt = time.time() - t0
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
-    # the reference's own CPU-runnable case beside it (BASELINE configs[0]: the 400x400 view, random-init weights,
-    # coarse pass only; what the "coarse_only_400" leg renders on the GPU), bounded too
     H0, W0, K0, c2w0, near0, far0 = synth.lego_camera(400, theta=30.0)
     o0, d0 = orc.get_rays(H0, W0, K0, c2w0)
     rays0 = orc.pack_rays(o0, d0, near0, far0, True)
-    n3 = min(n2 * 3, rays0.shape[0])
+    n3 = rays0.shape[0] if full else rays0.shape[0] // 8
+    sa = synth.make_state_dict(0, "A")
     t0 = time.time()
-    orc.render_rays(rays0[:n3], synth.make_state_dict(0, "A"), 64, 0, white_bkgd=True)
+    for i in range(0, n3, 32768):
+        orc.render_rays(rays0[i:i + 32768], sa, 64, 0, white_bkgd=True)
     dt3 = time.time() - t0
     return {"value": n2 / dt, "unit": "rays/s", "cores": int(cores), "kind": "port", "cpu": cpu_model(),
-            "sample": "first %d rays of the same 800x800 view, 64+128 samples, numpy oracle (float32, BLAS threads)" % n2,
-            "coarse_only": {"value": n3 / dt3, "unit": "rays/s",
-                            "sample": "first %d of the 160 000 rays of BASELINE configs[0] (400x400 view, 64 coarse "
-                                      "samples, no importance sampling)" % n3}}
+            "seconds": dt + dt3,
+            "sample": "%d rays from the middle rows of the same 800x800 view, 64+128 samples, numpy oracle (float32, %d BLAS "
+                      "threads)" % (n2, cores),
+            "coarse_only": {"value": n3 / dt3, "unit": "rays/s", "seconds": dt3,
+                            "sample": "%s rays of BASELINE configs[0] (400x400 view, 64 coarse samples, no importance "
+                                      "sampling, random-init weights)" % ("all 160 000" if n3 == 160000 else "the first %d" % n3)}}
 
 
 def cpu_model():
@@ -147,18 +152,19 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x2"])
     ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"],
                     help="train workload only: float32 (what the reference computes) or bf16 MFMA operands")
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--chunk", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-cpu-baseline", action="store_true", help="an eighth of the CPU baseline's two samples")
     ap.add_argument("--no-extras", action="store_true",
                     help="view workload: skip the fp32, 4M-ray and coarse-only legs that follow the headline region")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank joins the process group, rank 0 prints the world it sees; no "
                          "GPU work (checks the launcher, also on a machine without GPUs)")
-    ap.add_argument("--workload", default="view", choices=["view", "rays4m", "objects", "train", "coarse400"],
+    ap.add_argument("--workload", default="view", choices=["view", "view_a", "rays4m", "objects", "train", "coarse400"],
                     help="view: BASELINE configs[1] (default, the headline line); coarse400: configs[0], one 400x400 view with the "
                          "coarse network only; rays4m: configs[2], a 4 194 304-ray "
                          "batch split over the ranks; objects: configs[3], per-object networks dealt to the ranks; "
@@ -179,11 +185,16 @@ def resolve_world(gpus, environ):
     return ("launch", gpus) if gpus > 1 else ("rank", 1)
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, poll=0.2, grace=5.0):
     """Start n rank processes of this script (one per GPU, rendezvous on 127.0.0.1), relay rank 0's output and
-    return non-zero if any rank failed.  Nothing here initialises a GPU."""
+    return non-zero if any rank failed.  All children are watched: when one exits non-zero the others, which would
+    otherwise sit in the rendezvous or in a collective until its timeout, are terminated (killed after `grace`
+    seconds) and the job fails at once.  Output of ranks other than 0 goes to stderr.  Nothing here initialises a GPU.
+    The free port is found by binding and closing a socket: another process can take it before rank 0 binds it; that
+    rank then fails, which ends the job through the same path."""
     import socket
     import subprocess
+    import threading
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -192,14 +203,36 @@ def launch_ranks(n, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode("utf-8", "replace")
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(poll)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + grace
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=grace)
+    sys.stdout.write(b"".join(out0).decode("utf-8", "replace"))
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+    if failed:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s; the other ranks were stopped\n" % failed)
         return 1
     return 0
 
@@ -211,15 +244,20 @@ def make_workload(name, precision, args, rank, world, device):
     """-> dict(step, n_rays (this rank), total_rays (all ranks, per step), desc, scaling, flop_per_ray, parallelism)."""
     from nerf_loc_amd import dist as ndist, render, synth
     w = {"scaling": "weak", "flop_per_ray": 256 * FLOP_PER_SAMPLE, "precision": precision}
+    regime = "A" if name == "view_a" else "B"
+    if name == "view_a":
+        name = "view"
     if name in ("view", "rays4m"):
-        H, W, K, c2w, kwargs = build_scene(device, precision, args.res)
+        H, W, K, c2w, kwargs = build_scene(device, precision, args.res, regime=regime)
         rk = {k: v for k, v in kwargs.items() if k not in ("near", "far", "use_viewdirs", "ndc")}
         w["parallelism"] = "ray-shard x%d + 1 all-gather" % world
     if name == "view":
         n_rays = H * W
         w.update(n_rays=n_rays, total_rays=n_rays * world,
                  desc=("BASELINE configs[1]: %dx%d view (%d rays/GPU), 64 coarse + 128 importance samples, D8/W256 L10/4 "
-                       "viewdirs, separate fine net, seeded random weights, %s-MFMA mode" % (H, W, n_rays, precision)))
+                       "viewdirs, separate fine net, seeded random weights (%s), %s-MFMA mode"
+                       % (H, W, n_rays, "plain nn.Linear initialisation" if regime == "A" else
+                          "density and colour heads scaled up: opaque scene", precision)))
 
         def step():
             rays_flat, _ = render._build_rays(H, W, K, None, c2w, False, kwargs["near"], kwargs["far"], True, None)
@@ -340,12 +378,17 @@ def mlp_roofline(events, precision, dt, n_rays, traffic):
     """MFMA roofline of the network kernel from the HIP events of its launches: the largest launches (the fine pass)
     carry `achieved`; algorithmic FLOPs = samples x 1 186 816."""
     peak = PEAK_TFLOPS[precision]
-    kname = "mlp16_bf16_kernel" if precision == "bf16" else "mlp_f32_kernel"
+    kname = KERNEL[precision]
     ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
     flops = [n * FLOP_PER_SAMPLE for _, _, n in events]
     big = [(m, f) for m, f in zip(ms, flops) if f == max(flops)]
     ach = sum(f for _, f in big) / (sum(m for m, _ in big) * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+    issued = {}
+    if PRODUCTS[precision] > 1:      # algorithmic FLOPs stay the numerator; what the matrix cores execute is stated beside it
+        issued = {"issued": {"products_per_multiply_add": PRODUCTS[precision], "achieved": ach * PRODUCTS[precision],
+                             "frac": ach * PRODUCTS[precision] / peak,
+                             "note": "bf16 MFMA FLOPs executed, zero padding not counted; peak = dense bf16 MFMA"}}
+    return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, **issued,
             "traffic_unit": "HBM-side bytes per largest launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate "
                             "PMC passes of the default command)",
             "algorithmic_bytes": big[0][1] // FLOP_PER_SAMPLE * 20 + n_rays * 44,
@@ -362,6 +405,8 @@ def main(argv=None):
     if mode == "launch":
         raise SystemExit(launch_ranks(n, argv))
 
+    if os.environ.get("NERF_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):     # launcher test: this rank dies at once
+        raise SystemExit("bench.py: rank %s told to fail (NERF_BENCH_FAIL_RANK)" % os.environ.get("RANK", "0"))
     from nerf_loc_amd import dist as ndist, hip
     import torch.distributed as tdist
     if args.dry_run:
@@ -390,18 +435,19 @@ def main(argv=None):
     meta = {k: v for k, v in w.items() if k != "step"}
 
     extras = {}
-    if args.workload == "view" and not args.no_extras:
+    if args.workload in ("view", "view_a") and not args.no_extras:
         # the same view in the reference's own precision, and the 4M-ray strong-scaling batch, in this same run
         w = None      # drops the closure and with it the headline workload's device tensors
         torch.cuda.empty_cache()
-        for tag, wl, prec, st, wu in (("fp32", "view", "fp32", 2, 1), ("strong_4m", "rays4m", "bf16", 2, 1),
-                                      ("coarse_only_400", "coarse400", "bf16", 10, 2)):
-            if tag == "fp32" and precision == "fp32":
+        for tag, wl, prec, st, wu in (("fp32", "view", "fp32", 2, 1), ("bf16x3", "view", "bf16x3", 2, 1),
+                                      ("strong_4m", "rays4m", "bf16", 2, 1), ("coarse_only_400", "coarse400", "bf16", 10, 2),
+                                      ("view_random_init", "view_a", "bf16", 3, 1)):
+            if tag == precision:
                 continue
             x = make_workload(wl, prec, args, rank, world, device)
             dtx, evx, _ = timed(x["step"], st, wu, world, device)
             extras[tag] = {"value": x["total_rays"] * st / dtx, "unit": "rays/s", "ms_per_step": dtx / st * 1e3,
-                           "steps": st, "warmup": wu, "dtype": "f32" if prec == "fp32" else "bf16",
+                           "steps": st, "warmup": wu, "dtype": DTYPE[prec],
                            "scaling": x["scaling"], "rays_per_gpu": x["n_rays"], "workload": x["desc"],
                            "roofline": mlp_roofline(evx, prec, dtx, x["n_rays"],
                                                     pmc_traffic(prec) if wl == "view" else None)}
@@ -411,7 +457,7 @@ def main(argv=None):
     if rank == 0:
         peak = PEAK_TFLOPS[precision]
         if events:
-            roof = mlp_roofline(events, precision, dt, n_rays, pmc_traffic(precision) if args.workload == "view" else None)
+            roof = mlp_roofline(events, precision, dt, n_rays, pmc_traffic(precision) if args.workload in ("view", "view_a") else None)
         else:   # training: forward-with-tape, input-gradient and weight-gradient kernels, timed as a whole step
             ach = n_rays * meta["flop_per_ray"] * args.steps / dt / 1e12
             if precision == "bf16":
@@ -426,7 +472,7 @@ def main(argv=None):
                 roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                         "kernel": "whole iteration (mlp_f32_train_kernel + mlp_dgrad_f32_kernel + wgrad_kernel), "
                                   "3 x forward FLOPs per sample / step time"}
-        metric = {"view": "rendered rays/sec (64+128 samples)", "rays4m": "rendered rays/sec (64+128 samples)",
+        metric = {"view": "rendered rays/sec (64+128 samples)", "view_a": "rendered rays/sec (64+128 samples)", "rays4m": "rendered rays/sec (64+128 samples)",
                   "coarse400": "rendered rays/sec (64 samples, coarse only)",
                   "objects": "rendered rays/sec (64 samples, coarse only)",
                   "train": "training rays/sec (64+128 samples, fwd+bwd+Adam)"}[args.workload]
@@ -436,14 +482,14 @@ def main(argv=None):
             "n_gpus": world, "backend": backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": meta["scaling"], "vs_baseline": None,
-            "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": DTYPE[precision], "data": "synthetic",
             "config": {"workload": meta["desc"], "rays_per_gpu": n_rays, "chunk": args.chunk,
                        "parallelism": meta["parallelism"]},
             "roofline": roof,
         }
         line.update(extras)
         # the CPU figure is reported once, by the single-GPU run
-        line["cpu_baseline"] = None if (args.no_cpu_baseline or args.workload != "view" or world > 1) else cpu_baseline()
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or args.workload not in ("view", "view_a") or world > 1) else cpu_baseline(full=not args.quick_cpu_baseline)
         print(json.dumps(line))
     if world > 1:
         tdist.barrier()

@@ -59,3 +59,16 @@ def test_a_failing_rank_fails_the_job():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          env=_env(), capture_output=True, text=True, timeout=500, cwd=ROOT)
     assert out.returncode != 0 and "ranks failed" in out.stderr
+
+
+@pytest.mark.timeout(120)
+def test_one_dead_rank_stops_the_others_at_once():
+    """Rank 1 exits before the rendezvous; rank 0 would wait in it for minutes.  The launcher has to notice, stop rank
+    0 and return non-zero within seconds."""
+    import time
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         env=_env(NERF_BENCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=100, cwd=ROOT)
+    took = time.time() - t0
+    assert out.returncode != 0 and "ranks failed" in out.stderr and "(1, " in out.stderr, out.stdout + out.stderr
+    assert took < 60, took
