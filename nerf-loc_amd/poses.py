@@ -10,142 +10,155 @@ import zlib
 import numpy as np
 
 
-# ---------------------------------------------------------------------------- small vector helpers (load_llff.py:126-150)
+# ---------------------------------------------------------------------------- frames
+# A camera is a 3x4 frame [right | up | back | eye] (columns; the camera looks along -back), optionally with a fifth
+# column (height, width, focal).  Everything below works on stacks of frames at once; rigid frames are inverted as
+# [R^T | -R^T t], not through a general 4x4 inverse.
+def _unit(v):
+    v = np.asarray(v, dtype=np.float64)
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def _frames(back, up_hint, eye):
+    """Stack of frames [..., 3, 4] with the given viewing axes `back` [..., 3] (need not be unit), up hints and eyes."""
+    back = _unit(back)
+    right = _unit(np.cross(np.broadcast_to(up_hint, back.shape), back))
+    up = np.cross(back, right)                     # unit already: back and right are orthonormal
+    return np.stack([right, up, back, np.broadcast_to(np.asarray(eye, np.float64), back.shape)], -1)
+
+
+def _into_frame(frame, cams):
+    """Frames `cams` [N, 3, 4] expressed in the coordinates of the rigid `frame` [3, 4]."""
+    R, t = frame[:, :3], frame[:, 3]
+    out = np.empty(cams.shape, np.float64)
+    out[:, :, :3] = np.einsum('ji,njk->nik', R, cams[:, :, :3])
+    out[:, :, 3] = (cams[:, :, 3] - t) @ R
+    return out
+
+
+def _with_hwf(frames, hwf):
+    return np.concatenate([frames, np.broadcast_to(np.asarray(hwf, np.float64).reshape(3, 1), frames.shape[:-1] + (1,))], -1)
+
+
 def normalize(x):
-    return x / np.linalg.norm(x)
+    """x / |x| (load_llff.py:126-127)."""
+    return _unit(x)
 
 
 def viewmatrix(z, up, pos):
-    """3x4 camera-to-world frame looking along z with the given up hint, at pos."""
-    back = normalize(z)
-    right = normalize(np.cross(up, back))
-    true_up = normalize(np.cross(back, right))
-    return np.stack([right, true_up, back, pos], 1)
+    """3x4 camera-to-world frame looking along z with the given up hint, at pos (load_llff.py:129-136)."""
+    return _frames(np.asarray(z, np.float64), np.asarray(up, np.float64), pos)
 
 
 def ptstocam(pts, c2w):
-    return np.matmul(c2w[:3, :3].T, (pts - c2w[:3, 3])[..., np.newaxis])[..., 0]
+    """World points [..., 3] in the camera's coordinates (load_llff.py:138-140)."""
+    c2w = np.asarray(c2w, np.float64)
+    return (np.asarray(pts, np.float64) - c2w[:3, 3]) @ c2w[:3, :3]
 
 
 def poses_avg(poses):
-    """Average pose [3,5] of poses [N,3,5]: mean position, summed viewing and up axes; the hwf column of the first."""
-    hwf = poses[0, :3, -1:]
-    center = poses[:, :3, 3].mean(0)
-    back = normalize(poses[:, :3, 2].sum(0))
-    up = poses[:, :3, 1].sum(0)
-    return np.concatenate([viewmatrix(back, up, center), hwf], 1)
+    """Average camera [3,5] of poses [N,3,5] (load_llff.py:142-151): the mean eye, the frame spanned by the summed
+    viewing axes with the summed up axes as hint, and the (height, width, focal) column of the first pose."""
+    poses = np.asarray(poses)
+    frame = _frames(poses[:, :3, 2].sum(0, dtype=np.float64), poses[:, :3, 1].sum(0, dtype=np.float64),
+                    poses[:, :3, 3].mean(0, dtype=np.float64))
+    return _with_hwf(frame, poses[0, :3, 4])
 
 
 def render_path_spiral(c2w, up, rads, focal, zdelta, zrate, rots, N):
-    """N poses [3,5] on a spiral around c2w, all looking at the point `focal` in front of it (load_llff.py:155-164)."""
-    out = []
-    rads = np.array(list(rads) + [1.])
-    hwf = c2w[:, 4:5]
-    for theta in np.linspace(0., 2. * np.pi * rots, int(N) + 1)[:-1]:
-        offset = np.array([np.cos(theta), -np.sin(theta), -np.sin(theta * zrate), 1.]) * rads
-        eye = np.dot(c2w[:3, :4], offset)
-        target = np.dot(c2w[:3, :4], np.array([0, 0, -focal, 1.]))
-        out.append(np.concatenate([viewmatrix(normalize(eye - target), up, eye), hwf], 1))
-    return out
-
-
-def _to44(p):
-    last = np.tile(np.reshape(np.eye(4)[-1, :], [1, 1, 4]), [p.shape[0], 1, 1])
-    return np.concatenate([p, last], 1)
+    """N poses [3,5] on a spiral around the camera c2w, every one looking at the point `focal` in front of it
+    (load_llff.py:155-164): in camera coordinates the eye runs over (cos t, -sin t, -sin(zrate t)) * rads for t in
+    [0, 2 pi rots).  zdelta is accepted and unused, as in the reference.  Returns a list of N arrays."""
+    c2w = np.asarray(c2w, np.float64)
+    t = np.linspace(0., 2. * np.pi * rots, int(N) + 1)[:-1]
+    local = np.stack([np.cos(t), -np.sin(t), -np.sin(t * zrate)], -1) * np.asarray(rads, np.float64)[:3]
+    eyes = local @ c2w[:3, :3].T + c2w[:3, 3]
+    target = c2w[:3, 3] - focal * c2w[:3, 2]
+    return list(_with_hwf(_frames(eyes - target, np.asarray(up, np.float64), eyes), c2w[:3, 4]))
 
 
 def recenter_poses(poses):
-    """Expresses all poses in the frame of their average (load_llff.py:168-181); the hwf column is kept."""
-    out = poses + 0
-    avg = poses_avg(poses)
-    avg44 = np.concatenate([avg[:3, :4], np.reshape([0, 0, 0, 1.], [1, 4])], -2)
-    out[:, :3, :4] = (np.linalg.inv(avg44) @ _to44(poses[:, :3, :4]))[:, :3, :4]
-    return out
+    """All poses [N,3,5] in the coordinates of their average camera (load_llff.py:168-186); the hwf column is kept."""
+    poses = np.asarray(poses)
+    out = np.array(poses, dtype=np.float64)
+    out[:, :3, :4] = _into_frame(poses_avg(poses)[:3, :4], out[:, :3, :4])
+    return out.astype(poses.dtype)
 
 
 def spherify_poses(poses, bds):
-    """Inward-facing captures: recentre on the point closest to all optical axes, scale the cameras onto the unit
-    sphere, and return a 120-pose circle at their mean height (load_llff.py:188-245).  bds is scaled IN PLACE, like
-    the reference does.  Returns (poses_reset [N,3,5], circle [120,3,5], bds)."""
-    dirs = poses[:, :3, 2:3]
-    origins = poses[:, :3, 3:4]
-    A = np.eye(3) - dirs * np.transpose(dirs, [0, 2, 1])
-    b = -A @ origins
-    center = np.squeeze(-np.linalg.inv((np.transpose(A, [0, 2, 1]) @ A).mean(0)) @ b.mean(0))
-    up = (poses[:, :3, 3] - center).mean(0)
-    e0 = normalize(up)
-    e1 = normalize(np.cross([.1, .2, .3], e0))
-    e2 = normalize(np.cross(e0, e1))
-    frame = np.stack([e1, e2, e0, center], 1)
-    reset = np.linalg.inv(_to44(frame[None])) @ _to44(poses[:, :3, :4])
-    rad = np.sqrt(np.mean(np.sum(np.square(reset[:, :3, 3]), -1)))
-    sc = 1. / rad
-    reset[:, :3, 3] *= sc
-    bds *= sc
-    rad *= sc
-    zh = np.mean(reset[:, :3, 3], 0)[2]
-    radcircle = np.sqrt(rad ** 2 - zh ** 2)
-    circle = []
-    for th in np.linspace(0., 2. * np.pi, 120):
-        eye = np.array([radcircle * np.cos(th), radcircle * np.sin(th), zh])
-        back = normalize(eye)
-        right = normalize(np.cross(back, np.array([0, 0, -1.])))
-        down = normalize(np.cross(back, right))
-        circle.append(np.stack([right, down, back, eye], 1))
-    circle = np.stack(circle, 0)
-    hwf = poses[0, :3, -1:]
-    circle = np.concatenate([circle, np.broadcast_to(hwf, circle[:, :3, -1:].shape)], -1)
-    reset = np.concatenate([reset[:, :3, :4], np.broadcast_to(hwf, reset[:, :3, -1:].shape)], -1)
-    return reset, circle, bds
+    """Inward-facing captures (load_llff.py:189-245): origin at the point closest, in the least-squares sense, to all
+    optical axes; z along the mean offset of the cameras from it; cameras scaled so that their root-mean-square
+    distance is 1; plus a circle of 120 cameras at their mean height looking at the origin.  bds is scaled IN PLACE,
+    like the reference does.  Returns (poses [N,3,5], circle [120,3,5], bds)."""
+    poses = np.asarray(poses)
+    cams = np.array(poses[:, :3, :4], dtype=np.float64)
+    d, o = cams[:, :, 2], cams[:, :, 3]
+    # sum_i |P_i (c - o_i)|^2 -> min with P_i = I - d_i d_i^T: normal equations (mean P_i^T P_i) c = mean P_i^T P_i o_i
+    P = np.eye(3) - d[:, :, None] * d[:, None, :]
+    center = np.linalg.solve(np.einsum('nji,njk->ik', P, P) / len(P), np.einsum('nij,nj->i', P, o) / len(P))
+    e_z = _unit((o - center).mean(0))
+    e_x = _unit(np.cross([.1, .2, .3], e_z))       # the reference's helper direction fixes the in-plane orientation
+    e_y = np.cross(e_z, e_x)
+    cams = _into_frame(np.stack([e_x, e_y, e_z, center], -1), cams)
+    scale = 1. / np.sqrt(np.mean(np.sum(cams[:, :, 3] ** 2, -1)))
+    cams[:, :, 3] *= scale
+    bds *= scale
+    height = cams[:, 2, 3].mean()
+    ring = np.sqrt(1. - height ** 2)               # the scaled cameras have unit root-mean-square distance
+    th = np.linspace(0., 2. * np.pi, 120)
+    eyes = np.stack([ring * np.cos(th), ring * np.sin(th), np.full_like(th, height)], -1)
+    back = _unit(eyes)
+    right = _unit(np.cross(back, [0., 0., -1.]))
+    circle = np.stack([right, _unit(np.cross(back, right)), back, eyes], -1)
+    hwf = poses[0, :3, 4]
+    return _with_hwf(cams, hwf), _with_hwf(circle, hwf), bds
 
 
 # ---------------------------------------------------------------------------- poses_bounds.npy (load_llff.py:58-110, 247-316)
 def parse_poses_bounds(poses_arr, image_hw, pose_factor=1):
     """poses_bounds.npy [N,17] -> (poses [3,5,N], bds [2,N]) as _load_data leaves them: the hwf column gets the size
     of the images actually used and the focal length divided by pose_factor (load_llff.py:62-64, 103-105)."""
-    poses_arr = np.asarray(poses_arr)
-    poses = poses_arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0]).copy()
-    bds = poses_arr[:, -2:].transpose([1, 0]).copy()
-    poses[:2, 4, :] = np.array(image_hw[:2]).reshape([2, 1])
+    arr = np.asarray(poses_arr)
+    poses = np.ascontiguousarray(np.moveaxis(arr[:, :15].reshape(-1, 3, 5), 0, -1))
+    bds = np.ascontiguousarray(arr[:, 15:].T)
+    poses[0, 4, :], poses[1, 4, :] = image_hw[0], image_hw[1]
     poses[2, 4, :] = poses[2, 4, :] * 1. / pose_factor
     return poses, bds
 
 
 def llff_poses(poses, bds, recenter=True, bd_factor=.75, spherify=False, path_zflat=False):
-    """The pose half of load_llff_data (load_llff.py:251-316): axis reordering from the LLFF convention, rescaling by
-    the near bound, recentring, and the render path (spiral, or circle when spherify).  poses [3,5,N], bds [2,N] as
-    parse_poses_bounds returns them.  Returns (poses [N,3,5] float32, bds [N,2] float32, render_poses [M,3,5]
-    float32, i_test)."""
-    poses = np.concatenate([poses[:, 1:2, :], -poses[:, 0:1, :], poses[:, 2:, :]], 1)
-    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
-    bds = np.moveaxis(bds, -1, 0).astype(np.float32)
-    sc = 1. if bd_factor is None else 1. / (bds.min() * bd_factor)
-    poses[:, :3, 3] *= sc
-    bds *= sc
+    """The pose half of load_llff_data (load_llff.py:251-316).  poses [3,5,N], bds [2,N] as parse_poses_bounds returns
+    them.  LLFF stores the camera axes as (down, right, back): they become (right, up, back); the scene is scaled so
+    that the nearest depth bound is 1 / bd_factor; poses are recentred on their average; the render path is a two-turn
+    spiral of 120 poses (half a flat turn of 60 with path_zflat) or, with spherify, the circle of spherify_poses.
+    Returns (poses [N,3,5], bds [N,2], render_poses [M,3,5], i_test), arrays float32; i_test is the pose nearest to
+    the average camera."""
+    cams = np.moveaxis(np.asarray(poses), -1, 0).astype(np.float32)
+    cams = np.concatenate([cams[:, :, 1:2], -cams[:, :, 0:1], cams[:, :, 2:]], 2)
+    bds = np.ascontiguousarray(np.asarray(bds).T).astype(np.float32)
+    if bd_factor is not None:
+        scale = np.float32(1. / (bds.min() * bd_factor))
+        cams[:, :3, 3] *= scale
+        bds *= scale
     if recenter:
-        poses = recenter_poses(poses)
+        cams = recenter_poses(cams)
     if spherify:
-        poses, render_poses, bds = spherify_poses(poses, bds)
+        cams, path, bds = spherify_poses(cams, bds)
     else:
-        c2w = poses_avg(poses)
-        up = normalize(poses[:, :3, 1].sum(0))
-        close_depth, inf_depth = bds.min() * .9, bds.max() * 5.
-        dt = .75
-        focal = 1. / (((1. - dt) / close_depth + dt / inf_depth))
-        zdelta = close_depth * .2
-        rads = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
-        n_views, n_rots = 120, 2
+        centre = poses_avg(cams)
+        near, far = bds.min() * .9, bds.max() * 5.
+        focus = 1. / (.25 / near + .75 / far)      # a depth between the bounds, weighted towards the near one in disparity
+        radii = np.percentile(np.abs(cams[:, :3, 3]), 90, 0)
+        turns, count = 2, 120
         if path_zflat:
-            zloc = -close_depth * .1
-            c2w[:3, 3] = c2w[:3, 3] + zloc * c2w[:3, 2]
-            rads[2] = 0.
-            n_rots = 1
-            n_views /= 2
-        render_poses = render_path_spiral(c2w, up, rads, focal, zdelta, zrate=.5, rots=n_rots, N=n_views)
-    render_poses = np.array(render_poses).astype(np.float32)
-    c2w = poses_avg(poses)
-    i_test = int(np.argmin(np.sum(np.square(c2w[:3, 3] - poses[:, :3, 3]), -1)))
-    return poses.astype(np.float32), bds, render_poses, i_test
+            centre[:3, 3] += (-near * .1) * centre[:3, 2]
+            radii[2] = 0.
+            turns, count = 1, 60
+        path = render_path_spiral(centre, _unit(cams[:, :3, 1].sum(0)), radii, focus, near * .2, zrate=.5, rots=turns,
+                                  N=count)
+    cams = np.asarray(cams, np.float32)
+    nearest = int(np.argmin(np.sum((poses_avg(cams)[:3, 3] - cams[:, :3, 3]) ** 2, -1)))
+    return cams, bds, np.asarray(path, np.float32), nearest
 
 
 # ---------------------------------------------------------------------------- load_blender.py:15-34
