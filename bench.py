@@ -322,20 +322,23 @@ def make_workload(name, precision, args, rank, world, device):
         lo, hi, _ = ndist.shard_bounds(total, rank, world)
         rays_l, tgt_l = rays_all[lo:hi], tgt_all[lo:hi]
         train.set_train_precision(args.train_precision)
+        ndist.seed_ranks(0)            # every rank draws its own stratified jitter
+        ex = ndist.GradientExchange([kwargs["network_fn"], kwargs["network_fine"]])
         w.update(scaling="strong", n_rays=hi - lo, total_rays=total, flop_per_ray=3 * 256 * FLOP_PER_SAMPLE,
-                 precision=args.train_precision, parallelism="data parallel x%d, 1 gradient all-reduce" % world,
+                 precision=args.train_precision, parallelism="data parallel x%d, in-place gradient all-reduce per network, the fine network's under the "
+                                                      "coarse network's backward" % world,
                  desc=("BASELINE configs[4]: training iteration, 4096 rays over %d GPU(s), 64 + 128 samples, stratified "
-                       "jitter, forward + backward of both networks + one gradient all-reduce + Adam, %s"
+                       "jitter, forward + backward of both networks + gradient all-reduce + Adam, %s"
                        % (world, "float32" if args.train_precision == "fp32" else
                           "bf16 operands, float32 accumulation and parameters")))
         it = [0]
 
         def step():
             ret = render.batchify_rays(rays_l, 1 << 20, **rk)
-            opt.zero_grad()
+            ex.begin(n_local=hi - lo, n_global=total)          # in place of optimizer.zero_grad(): one fill
             loss = helpers.img2mse(ret["rgb_map"], tgt_l) + helpers.img2mse(ret["rgb0"], tgt_l)
-            loss.backward()
-            ndist.average_gradients([kwargs["network_fn"], kwargs["network_fine"]], n_local=hi - lo, n_global=total)
+            loss.backward()                                    # writes into the exchange's buffer; the fine network's
+            ex.finish()                                        # all-reduce runs under the coarse network's backward
             opt.step()
             it[0] += 1
             for g in opt.param_groups:

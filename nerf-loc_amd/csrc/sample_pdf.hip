@@ -63,7 +63,7 @@ __device__ float row_sum_aten(const float* x, int n, int stride) {
 }
 
 struct SamplePdfArgs {
-    int skip_if_grid;      // fast kernel: leave at once when the variates are the ascending grid (the row kernel ran)
+    int group;             // rays a wavefront of the bisection kernels takes together, 1 .. PDF_GROUP (few rays: more waves)
     const float* bins; int bins_stride; int bins_are_z; int nb;
     const float* weights; int w_stride;
     const float* u; int n_u; int u_per_ray; int R;
@@ -170,16 +170,15 @@ __device__ __forceinline__ int count_fixed(const float* a, float v) {
 
 __device__ __forceinline__ bool variates_on_grid(const float* u, int lane);
 
-__global__ __launch_bounds__(64) void sample_pdf_fast_kernel(SamplePdfArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x;
-    if (a.skip_if_grid && variates_on_grid(a.u, lane)) return;     // sample_pdf_row_kernel took this launch's rays
+constexpr int FAST_LDS = PDF_GROUP * FAST_SC + 64 + FAST_NU + FAST_NZ;      // floats
+
+// One group of a.group rays, rays r0 ...; smem: FAST_LDS floats.  Ends with a workgroup barrier.
+__device__ __forceinline__ void sample_pdf_fast_group(const SamplePdfArgs& a, float* smem, long long r0, int lane) {
     float* cdf_g = smem;                                      // [PDF_GROUP][63]
     float* bins_s = cdf_g + PDF_GROUP * FAST_SC;              // 64 (63 used)
     float* zs_s = bins_s + 64;                                // 128
     float* zc_s = zs_s + FAST_NU;                             // 64
-    const long long r0 = (long long)blockIdx.x * PDF_GROUP;
-    const int n_live = (int)(a.R - r0 < PDF_GROUP ? a.R - r0 : PDF_GROUP);
+    const int n_live = (int)(a.R - r0 < a.group ? a.R - r0 : a.group);
     build_cdf_rows(a, cdf_g, FAST_SC, r0, n_live, lane);
     const float u0 = a.u[lane], u1 = a.u[lane + 64];
 
@@ -258,6 +257,11 @@ __global__ __launch_bounds__(64) void sample_pdf_fast_kernel(SamplePdfArgs a) {
     }
 }
 
+__global__ __launch_bounds__(64) void sample_pdf_fast_kernel(SamplePdfArgs a, int n_groups) {
+    __shared__ __attribute__((aligned(16))) float smem[FAST_LDS];
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) sample_pdf_fast_group(a, smem, (long long)grp * a.group, threadIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // The same shape when the shared variates ascend along the regular grid k / 127 (what render_rays passes when it does
 // not perturb: torch.linspace(0, 1, 128), run_nerf_helpers.py:210-212; also numpy.linspace of the pytest hook): ONE 16-LANE ROW PER RAY, four rays per
@@ -307,10 +311,17 @@ __device__ __forceinline__ bool variates_on_grid(const float* u, int lane) {
                  fabsf(ub * 127.0f - (float)(2 * lane + 1)) <= 1e-3f);
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NERF_ROW_WAVES))) void sample_pdf_row_kernel(SamplePdfArgs a, int n_quads) {
+static_assert(4 * ROW_LDS + FAST_NU >= FAST_LDS, "the bisection path fits the row kernel's LDS");
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NERF_ROW_WAVES))) void sample_pdf_row_kernel(SamplePdfArgs a, int n_quads,
+                                                                                                              int n_groups) {
     __shared__ __attribute__((aligned(16))) float smem[4 * ROW_LDS + FAST_NU];
     const int lane = threadIdx.x, j = lane & 15, row = lane >> 4, row0 = lane & 48;
-    if (!variates_on_grid(a.u, lane)) return;                  // the bisection kernel, launched next, does the work
+    if (!variates_on_grid(a.u, lane)) {
+        // any other shared variates: the bisection path, in this same launch (decided on the device: the host never
+        // sees the variates), groups of a.group rays dealt to the workgroups
+        for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) sample_pdf_fast_group(a, smem, (long long)grp * a.group, lane);
+        return;
+    }
     float* u_s = smem + 4 * ROW_LDS;
     u_s[lane] = a.u[lane];
     u_s[lane + 64] = a.u[lane + 64];
@@ -639,8 +650,8 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void sample_pdf_kernel(SamplePdfArg
     // coarse depths and bins come from the same array: the rank of a sample among the coarse depths follows from
     // its bin (checked, with the binary search as fallback)
     const bool z_is_bins = a.bins_are_z && a.z_sorted && a.z_vals == a.bins && a.n_z == nb + 1;
-    const long long r0 = ((long long)blockIdx.x * PDF_WAVES + wv) * PDF_GROUP;
-    const int n_live = (int)(a.R - r0 < PDF_GROUP ? a.R - r0 : PDF_GROUP);
+    const long long r0 = ((long long)blockIdx.x * PDF_WAVES + wv) * a.group;
+    const int n_live = (int)(a.R - r0 < a.group ? a.R - r0 : a.group);
 
     build_cdf_rows(a, cdf_g, sc, r0, n_live, lane);
 
@@ -751,28 +762,31 @@ extern "C" int nerf_sample_pdf(const float* bins, int bins_stride, int bins_are_
                  "nerf_sample_pdf: row strides shorter than the rows");
     if (z_sorted) NERF_REQUIRE(z_vals && n_z >= 1, "nerf_sample_pdf: z_sorted needs z_vals");
     if (R == 0) return NERF_OK;
-    SamplePdfArgs a{0, bins, bins_stride, bins_are_z, nb, weights, w_stride, u, n_u, u_per_ray, R,
+    // The serial phases run one ray per lane for a group of rays and the rest ray by ray: with few rays (a training
+    // batch) smaller groups give more wavefronts and a shorter critical path (512 rays: 0.257 ms with groups of 16).
+    int group = R / 2048;
+    group = group < 1 ? 1 : (group > PDF_GROUP ? PDF_GROUP : group);
+    SamplePdfArgs a{group, bins, bins_stride, bins_are_z, nb, weights, w_stride, u, n_u, u_per_ray, R,
                     z_vals, n_z, z_samples, inds, z_sorted, z_std};
+    const int n_groups = (R + group - 1) / group;
     if (nb == FAST_NB && n_u == FAST_NU && !u_per_ray && bins_are_z && z_sorted && z_vals == bins && n_z == FAST_NZ) {
-        // two launches that decide on the device which of them works: the row kernel when the variates are the
-        // regular ascending grid, else the bisection kernel; the other one leaves after reading the 128 variates
+        // ONE launch: the row kernel works when the variates are the regular ascending grid and runs the bisection path
+        // itself otherwise (decided on the device); outputs that are not 16-byte aligned go to the bisection kernel
         if ((((uintptr_t)z_samples | (uintptr_t)inds | (uintptr_t)z_sorted) & 15) == 0) {
             const int n_quads = (R + 3) / 4;
             hipLaunchKernelGGL(sample_pdf_row_kernel, dim3(n_quads < 16384 ? n_quads : 16384), dim3(WAVE), 0, as_stream(stream), a,
-                               n_quads);
-            NERF_LAUNCH_CHECK();
-            a.skip_if_grid = 1;
+                               n_quads, n_groups);
+        } else {
+            hipLaunchKernelGGL(sample_pdf_fast_kernel, dim3(n_groups < 65536 ? n_groups : 65536), dim3(WAVE), 0, as_stream(stream),
+                               a, n_groups);
         }
-        const size_t fast_shmem = ((size_t)PDF_GROUP * FAST_SC + 64 + FAST_NU + FAST_NZ) * sizeof(float);
-        hipLaunchKernelGGL(sample_pdf_fast_kernel, dim3((R + PDF_GROUP - 1) / PDF_GROUP), dim3(WAVE), fast_shmem,
-                           as_stream(stream), a);
         NERF_LAUNCH_CHECK();
         return NERF_OK;
     }
     const size_t per_wave = (size_t)PDF_GROUP * (nb | 1) + nb + 2 * (size_t)n_u + (z_sorted ? n_z : 0);
     const size_t shmem = per_wave * PDF_WAVES * sizeof(float);
     NERF_REQUIRE(shmem <= 64 * 1024, "nerf_sample_pdf: rows too long for the LDS staging (%zu bytes)", shmem);
-    const int rays_per_block = PDF_WAVES * PDF_GROUP;
+    const int rays_per_block = PDF_WAVES * group;
     dim3 grid((R + rays_per_block - 1) / rays_per_block), block(PDF_WAVES * WAVE);
     hipLaunchKernelGGL(sample_pdf_kernel, grid, block, shmem, as_stream(stream), a);
     NERF_LAUNCH_CHECK();

@@ -2,6 +2,7 @@
 // dimension (what autograd computes for the Linear layers of run_nerf_helpers.py:67-119 in loss.backward(),
 // run_nerf.py:785).  Kept in its own translation unit: the 256 accumulator registers of a wave live in AGPRs here,
 // whereas the layer-chain kernels are compiled with accumulators in arch VGPRs.
+#include <stdlib.h>
 #include "wgrad.h"
 #include "mlp_layout.h"
 #include "mlp_device.h"
@@ -269,6 +270,17 @@ __global__ __launch_bounds__(64 * RED_SPLIT) void wgrad_reduce_kernel(ReduceArgs
     a.dst[(size_t)row * a.ld + a.col_off + dc] = sum;
 }
 
+// NERF_WG_MIN_CHUNK (environment, read once): tuning experiments only
+static long long wg_min_chunk() {
+    static long long v = 0;
+    if (v == 0) {
+        const char* e = getenv("NERF_WG_MIN_CHUNK");
+        long long x = e ? atoll(e) : 128;
+        v = x >= 2 ? x : 128;
+    }
+    return v;
+}
+
 int launch_wgrad_reduce(const float* ws, int parts, int pcol, int pcol0, int n_rows, int k_emit, float* dW, int ld,
                         int col_off, int map, const float* x_scale, float* db, hipStream_t st) {
     ReduceArgs r{ws + pcol0, parts, 256, pcol, n_rows, k_emit, dW, ld, col_off, map, x_scale,
@@ -286,7 +298,9 @@ int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K,
                  "weight gradient: unsupported shape %d x %d", N, K);
     NERF_REQUIRE(ldg % 2 == 0 && ldx % 4 == 0 && ((uintptr_t)G & 7) == 0 && ((uintptr_t)X & 15) == 0,
                  "weight gradient: rows of G / X must be 8- / 16-byte aligned (ldg %d, ldx %d)", ldg, ldx);
-    long long parts = (M + 511) / 512;             // at least 512 samples per workgroup
+    // Samples per workgroup: at least wg_min_chunk().  Fewer workgroups write fewer partial tiles (256 KB each), but a
+    // 512-ray shard of a data-parallel batch (32 768 coarse samples) then keeps only 64 of 256 compute units busy.
+    long long parts = (M + wg_min_chunk() - 1) / wg_min_chunk();
     if (parts > WG_MAX_PARTS) parts = WG_MAX_PARTS;
     if (parts > cu_count()) parts = cu_count();
     if (parts < 1) parts = 1;

@@ -152,6 +152,122 @@ def average_gradients(modules, n_local=None, n_global=None):
     return o
 
 
+class _ArenaSlot:
+    """What a module knows about its share of a GradientExchange: its gradient views (parameter order) and whether
+    they still wait for this step's gradient."""
+
+    def __init__(self, exchange, index, params, views):
+        self.exchange, self.index, self.params, self.views = exchange, index, params, views
+        self.fresh = True
+
+    def view_of(self, p):
+        for q, v in zip(self.params, self.views):
+            if q is p:
+                return v
+        return None
+
+    def attach(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+
+    def written(self):
+        """The module's gradient of this step is complete in its views (written in place by the backward kernels)."""
+        self.fresh = False
+        self.exchange.module_ready(self.index)
+
+
+class GradientExchange:
+    """Data-parallel gradient exchange without copies, overlapped with the backward pass.
+
+    All gradients of the given modules (coarse + fine network: 1 191 688 floats) live in ONE flat float32 buffer;
+    every parameter's .grad is a view of it, so the all-reduce runs in place: no concatenation before, no copies
+    after.  The buffer is cut per module: as soon as a module's gradient is complete (the HIP backward writes it
+    straight into the views and reports it; loss.backward() runs the fine network's backward first, run_nerf.py:785)
+    its slice is scaled by this rank's weight n_local / n_global and all-reduced asynchronously, while the other
+    network's backward is still running on the compute stream; finish() exchanges whatever is left and waits.
+    Per step:  ex.begin(n_local, n_global); loss.backward(); ex.finish(); optimizer.step().
+    A world of one exchanges nothing and still saves the per-step gradient allocations."""
+
+    def __init__(self, modules):
+        self.modules = list(modules)
+        params = [[p for p in m.parameters() if p.requires_grad] for m in self.modules]
+        first = next((p for ps in params for p in ps), None)
+        if first is None:
+            raise ValueError("GradientExchange: no parameter requires grad")
+        total = sum(p.numel() for ps in params for p in ps)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=first.device)
+        self.bounds, self.slots = [], []
+        o = 0
+        for i, (m, ps) in enumerate(zip(self.modules, params)):
+            start, views = o, []
+            for p in ps:
+                if p.dtype != torch.float32 or p.device != first.device:
+                    raise ValueError("GradientExchange: parameters must be float32 on one device")
+                views.append(self.flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            self.bounds.append((start, o))
+            slot = _ArenaSlot(self, i, ps, views)
+            slot.attach()
+            m._grad_arena = slot
+            self.slots.append(slot)
+        self.weight = 1.0
+        self._pending = []
+        self._sent = [False] * len(self.modules)
+
+    def begin(self, n_local=None, n_global=None):
+        """Start of a step (in place of optimizer.zero_grad()): clears the buffer with one fill and fixes this rank's
+        weight, n_local / n_global rays of the global batch (equal shards when omitted)."""
+        if (n_local is None) != (n_global is None):
+            raise ValueError("GradientExchange.begin: pass both n_local and n_global, or neither")
+        g = world()
+        self.weight = (1.0 / g if n_local is None else float(n_local) / float(n_global)) if g > 1 else 1.0
+        self.flat.zero_()
+        self._pending = []
+        self._sent = [False] * len(self.modules)
+        for s in self.slots:
+            s.attach()
+            s.fresh = True
+
+    zero_grad = begin
+
+    def module_ready(self, index):
+        """Module `index` has its complete local gradient in its slice: exchange it now, asynchronously."""
+        if world() == 1 or self._sent[index]:
+            return
+        self._sent[index] = True
+        lo, hi = self.bounds[index]
+        part = self.flat[lo:hi]
+        if self.weight != 1.0:
+            part.mul_(self.weight)
+        if part.is_cuda and dist.get_backend() == "gloo":     # CPU rehearsal of a GPU job: through host memory
+            host = part.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            part.copy_(host)
+            return
+        # RCCL: the collective is ordered after everything enqueued on the current stream so far and runs on the
+        # communicator's own stream; the compute stream goes on with the other network's backward
+        self._pending.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """Exchanges the slices nobody reported, then makes the current stream wait for all of them.  Returns the
+        number of gradient elements this rank holds (all of them global sums afterwards)."""
+        for i in range(len(self.modules)):
+            self.module_ready(i)
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        return self.flat.numel()
+
+
+def seed_ranks(seed):
+    """Seeds torch's generators (CPU and every GPU) with seed + rank: the stratified jitter and the density noise of
+    a data-parallel step (torch.rand / torch.randn in render_rays, run_nerf.py:377, 291) must differ between the
+    shards of one batch; a world of one keeps `seed`."""
+    torch.manual_seed(int(seed) + rank())
+    return int(seed) + rank()
+
+
 def shard_batch(rays, target):
     """This rank's contiguous share of a training batch (rays [N, C], target [N, 3])."""
     lo, hi, _ = shard_bounds(rays.shape[0], rank(), world())

@@ -478,9 +478,10 @@ def mlp_forward_train(packed, use_viewdirs, output_ch, mode, in0, in1, R, S, ray
 _WORKSPACE = {}
 
 
-def mlp_backward(packed_bwd, use_viewdirs, output_ch, d_raw, tape, shapes, precision="fp32", packed_fwd=None):
+def mlp_backward(packed_bwd, use_viewdirs, output_ch, d_raw, tape, shapes, precision="fp32", packed_fwd=None, out=None):
     """Gradients of the parameter tensors: list in state_dict order shaped like `shapes` (None entries are
-    skipped and come back as None).  bf16: packed_fwd is the forward stream the tape was made with."""
+    skipped and come back as None).  bf16: packed_fwd is the forward stream the tape was made with.  out: tensors to
+    write the gradients into (contiguous float32, e.g. views of one flat buffer) instead of new ones."""
     prec = PRECISIONS[precision]
     if precision == "bf16" and packed_fwd is None:
         raise ValueError("mlp_backward: the bf16 backward needs packed_fwd")
@@ -488,7 +489,18 @@ def mlp_backward(packed_bwd, use_viewdirs, output_ch, d_raw, tape, shapes, preci
     dev = d_raw.device
     M = d_raw.numel() // output_ch
     vd = int(bool(use_viewdirs))
+    if out is not None:
+        _need(len(out) == len(shapes) and all((g is None) == (s is None) for g, s in zip(out, shapes)),
+              "mlp_backward: `out` does not match the parameter list")
+        _need(all(g is None or (g.is_cuda and g.device == dev and g.dtype == torch.float32 and g.is_contiguous() and
+                                tuple(g.shape) == tuple(s)) for g, s in zip(out, shapes)),
+              "mlp_backward: `out` tensors must be contiguous float32 on %s, shaped like the parameters", dev)
     if M == 0:      # an empty shard of a data-parallel batch: zero gradients, so the all-reduce still lines up
+        if out is not None:
+            for g in out:
+                if g is not None:
+                    g.zero_()
+            return list(out)
         return [None if s is None else torch.zeros(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
     _need(tape.is_cuda and tape.device == dev and tape.numel() * tape.element_size() >= lib().nerf_train_tape_bytes(M, vd, prec),
           "mlp_backward: the tape does not belong to a forward of %d samples on %s", M, dev)
@@ -497,7 +509,8 @@ def mlp_backward(packed_bwd, use_viewdirs, output_ch, d_raw, tape, shapes, preci
     if ws is None:
         ws = _WORKSPACE[str(dev)] = torch.empty((lib().nerf_train_workspace_bytes() // 4,), dtype=torch.float32,
                                                 device=dev)
-    grads = [None if s is None else torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    grads = list(out) if out is not None else [None if s is None else torch.empty(tuple(s), dtype=torch.float32, device=dev)
+                                               for s in shapes]
     arr = (ctypes.c_void_p * len(grads))(*[None if g is None else g.data_ptr() for g in grads])
     with torch.cuda.device(dev):
         _check(lib().nerf_mlp_backward(ctypes.c_void_p(packed_bwd.data_ptr()),

@@ -85,6 +85,9 @@ class _NetworkFn(torch.autograd.Function):
                                           precision=prec)
         ctx.tape = tape
         ctx.prec = prec
+        ctx.model = model
+        ctx.slots = slots
+        ctx.param_list = full
         ctx.packed_fwd = packed
         ctx.packed_bwd = _packed_backward(model, full, prec)
         ctx.shapes = [None if p is None else tuple(p.shape) for p in full]
@@ -93,6 +96,21 @@ class _NetworkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_raw):
+        # A module whose gradients live in a dist.GradientExchange buffer and still wait for this step's gradient: the
+        # kernels write straight into the parameters' .grad views (no allocation, no accumulation pass) and the
+        # exchange is told, so that it can start this network's all-reduce under the other network's backward.
+        slot = getattr(ctx.model, "_grad_arena", None)
+        if slot is not None:
+            views = [None if p is None else slot.view_of(p) for p in ctx.param_list]
+            direct = all((p is None) == (v is None) for p, v in zip(ctx.param_list, views)) and \
+                (slot.fresh or all(p is None or p.grad is None for p in ctx.param_list))
+            if direct:
+                hip.mlp_backward(ctx.packed_bwd, ctx.arch[0], ctx.arch[1], g_raw.contiguous(), ctx.tape, ctx.shapes,
+                                 precision=ctx.prec, packed_fwd=ctx.packed_fwd, out=views)
+                ctx.tape = None
+                slot.attach()
+                slot.written()
+                return (None,) * (8 + sum(1 for p in ctx.param_list if p is not None))
         grads = hip.mlp_backward(ctx.packed_bwd, ctx.arch[0], ctx.arch[1], g_raw.contiguous(), ctx.tape, ctx.shapes,
                                  precision=ctx.prec, packed_fwd=ctx.packed_fwd)
         ctx.tape = None
@@ -263,21 +281,29 @@ class FusedAdam(torch.optim.Optimizer):
 
 
 # ---------------------------------------------------------------------------- the step itself (run_nerf.py:770-796)
-def train_step(rays, target, render_kwargs, optimizer, global_step, lrate, lrate_decay, chunk=1024 * 32):
+def train_step(rays, target, render_kwargs, optimizer, global_step, lrate, lrate_decay, chunk=1024 * 32, exchange=None,
+               n_global=None):
     """One optimisation step as the reference's loop body does it: render the ray batch [N, 8|11], loss =
     img2mse(rgb, target) (+ img2mse(rgb0, target)), backward, optimizer.step(), then the exponential learning-rate
-    decay 0.1 ** (global_step / (lrate_decay * 1000)).  Returns (loss, psnr) as tensors."""
+    decay 0.1 ** (global_step / (lrate_decay * 1000)).  Returns (loss, psnr) as tensors.
+    exchange: a dist.GradientExchange over the networks (data-parallel training, or just allocation-free gradients on
+    one GPU); `rays` is then this rank's shard of a global batch of n_global rays (default: equal shards)."""
     from .helpers import img2mse, mse2psnr
     from .render import batchify_rays
     kw = {k: v for k, v in render_kwargs.items() if k not in ("near", "far", "use_viewdirs", "ndc")}
     ret = batchify_rays(rays, chunk, **kw)
-    optimizer.zero_grad()
+    if exchange is None:
+        optimizer.zero_grad()
+    else:
+        exchange.begin(*(() if n_global is None else (rays.shape[0], n_global)))
     img_loss = img2mse(ret['rgb_map'], target)
     loss = img_loss
     psnr = mse2psnr(img_loss.detach())
     if 'rgb0' in ret:
         loss = loss + img2mse(ret['rgb0'], target)
     loss.backward()
+    if exchange is not None:
+        exchange.finish()
     optimizer.step()
     new_lrate = lrate * (0.1 ** (global_step / (lrate_decay * 1000)))
     for group in optimizer.param_groups:

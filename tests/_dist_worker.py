@@ -77,6 +77,35 @@ def main():
         want = torch.cat([p.grad.reshape(-1) for m in nets for p in m.parameters()])
         res["dp_ragged"][str(total)] = {"ok": bool(n == got.numel() and torch.allclose(got, want, atol=1e-6)),
                                         "shard": int(xs.shape[0])}
+    # the copy-free exchange: gradients live in one flat buffer, each module's slice is all-reduced in place, the
+    # second module's as soon as it is reported (what the HIP backward does for the network that finishes first)
+    ex = ndist.GradientExchange(nets)
+    res["ex"] = {"views": bool(all(p.grad.data_ptr() >= ex.flat.data_ptr() and
+                                   p.grad.data_ptr() < ex.flat.data_ptr() + ex.flat.numel() * 4 for m in nets for p in m.parameters()))}
+    for total in (8, 15, 1):
+        x = torch.randn(total, 5, generator=torch.Generator().manual_seed(31))
+        y = torch.randn(total, 2, generator=torch.Generator().manual_seed(32))
+        xs, ys = ndist.shard_batch(x, y)
+        ex.begin(n_local=xs.shape[0], n_global=total)
+        if xs.shape[0]:
+            ((nets[1](torch.relu(nets[0](xs))) - ys) ** 2).mean().backward()      # autograd adds into the views
+        ptrs = [p.grad.data_ptr() for m in nets for p in m.parameters()]
+        ex.module_ready(1)                      # the head's gradient goes out first, asynchronously
+        n = ex.finish()
+        got = ex.flat.clone()
+        same_storage = ptrs == [p.grad.data_ptr() for m in nets for p in m.parameters()]
+        ref = [torch.nn.Linear(5, 3), torch.nn.Linear(3, 2)]
+        for a, b in zip(ref, nets):
+            a.load_state_dict(b.state_dict())
+        ((ref[1](torch.relu(ref[0](x))) - y) ** 2).mean().backward()
+        want = torch.cat([p.grad.reshape(-1) for m in ref for p in m.parameters()])
+        res["ex"][str(total)] = {"ok": bool(n == want.numel() and torch.allclose(got, want, atol=1e-6)),
+                                 "in_place": bool(same_storage), "shard": int(xs.shape[0])}
+    # per-rank random streams: the ranks of one job must not draw the same jitter
+    s_used = ndist.seed_ranks(1234)
+    draw = torch.rand(4)
+    torch.manual_seed(1234)
+    res["seed"] = {"used": s_used, "draw": draw.tolist(), "rank0_draw": torch.rand(4).tolist()}
     torch.distributed.barrier()
     with open(out_path + ".%d" % rank, "w") as f:
         json.dump(res, f)

@@ -77,7 +77,38 @@ def test_world_size_two_gloo(tmp_path):
         assert x["dp_ragged"]["15"] == {"ok": True, "shard": 8 - r} and x["dp_ragged"]["1"] == {"ok": True, "shard": 1 - r}
         for n, c in x["cases"].items():
             assert c["ok"], (r, n, c)
+        assert x["ex"]["views"]
+        for total, shard in (("8", 4), ("15", 8 - r), ("1", 1 - r)):
+            assert x["ex"][total] == {"ok": True, "in_place": True, "shard": shard}, (r, total, x["ex"][total])
+        assert x["seed"]["used"] == 1234 + r
+    assert res[0]["seed"]["draw"] == res[0]["seed"]["rank0_draw"]         # rank 0 of a job = the single-process stream
+    assert res[1]["seed"]["draw"] != res[0]["seed"]["draw"]
     # n = 1: rank 1 holds an empty shard and renders only a 1-ray probe for the key list
     assert res[0]["cases"]["1"]["rendered"] == [1] and res[1]["cases"]["1"]["shard"][:2] == [1, 1]
     assert res[0]["cases"]["1001"]["rendered"] == [501] and res[1]["cases"]["1001"]["rendered"] == [500]
     assert res[0]["objects"] == [0, 2, 4] and res[1]["objects"] == [1, 3]
+
+
+def test_gradient_exchange_world_of_one():
+    """Without a process group the exchange only provides the flat storage: gradients accumulate into views of one
+    buffer, begin() clears it with one fill, finish() changes nothing."""
+    torch.manual_seed(0)
+    nets = [torch.nn.Linear(5, 3), torch.nn.Linear(3, 2)]
+    ex = ndist.GradientExchange(nets)
+    x, y = torch.randn(6, 5), torch.randn(6, 2)
+    ex.begin()
+    ((nets[1](torch.relu(nets[0](x))) - y) ** 2).mean().backward()
+    got = ex.flat.clone()
+    assert ex.finish() == got.numel() == sum(p.numel() for m in nets for p in m.parameters())
+    assert torch.equal(ex.flat, got)
+    for m in nets:
+        m.zero_grad(set_to_none=True)
+    ((nets[1](torch.relu(nets[0](x))) - y) ** 2).mean().backward()
+    want = torch.cat([p.grad.reshape(-1) for m in nets for p in m.parameters()])
+    assert torch.allclose(got, want, atol=1e-7)
+    ex.begin()                                   # re-attaches the views that zero_grad(set_to_none) dropped
+    assert float(ex.flat.abs().max()) == 0.0
+    assert all(p.grad.data_ptr() >= ex.flat.data_ptr() for m in nets for p in m.parameters())
+    with pytest.raises(ValueError):
+        ex.begin(n_local=3)
+    assert ndist.seed_ranks(7) == 7

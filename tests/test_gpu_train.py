@@ -356,3 +356,45 @@ def test_train_step_without_view_directions_matches_reference_autograd(dev, gold
         for n, ref in zip([str(x) for x in g[pre + "_names"]], g[pre + "_gradnorm"]):
             assert abs(float(np.linalg.norm(grads[n])) - ref) <= 2e-3 * max(ref, 1e-6), (pre, n)
         print("  %s network: worst gradient error relative to the tensor's largest entry %.2e" % (pre, worst))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_gradient_exchange_direct_write_equals_autograd_path(dev, precision):
+    """With a dist.GradientExchange the backward kernels write into views of one flat buffer and autograd sees no
+    parameter gradients at all: same bits as the ordinary path (fresh tensors handed to autograd), .grad of every
+    parameter a view of the buffer, a second step after begin() equal to the first, and the unused views_linears of a
+    network without view directions left at zero."""
+    from nerf_loc_amd import dist as ndist, helpers, render, train
+    rays = T(synth.random_rays(96, seed=9), dev)
+    target = torch.rand(96, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    nc, nf = load_net(synth.make_state_dict(80, "B"), dev), load_net(synth.make_state_dict(81, "B"), dev)
+    for n in (nc, nf):
+        n.train_precision = precision
+    kw = dict(network_query_fn=_query(dev), perturb=0.0, N_importance=128, network_fine=nf, N_samples=64, network_fn=nc,
+              white_bkgd=True, raw_noise_std=0.0)
+
+    def run():
+        ret = render.batchify_rays(rays, 1 << 20, **kw)
+        (helpers.img2mse(ret["rgb_map"], target) + helpers.img2mse(ret["rgb0"], target)).backward()
+
+    run()
+    want = torch.cat([p.grad.reshape(-1) for m in (nc, nf) for p in m.parameters()]).clone()
+    ex = ndist.GradientExchange([nc, nf])
+    for rep in range(2):
+        ex.begin()
+        run()
+        assert ex.finish() == want.numel()
+        assert torch.equal(ex.flat, want), (precision, rep, float((ex.flat - want).abs().max()))
+        assert not nc._grad_arena.fresh and not nf._grad_arena.fresh          # both went through the direct path
+    lo, hi = ex.flat.data_ptr(), ex.flat.data_ptr() + 4 * ex.flat.numel()
+    assert all(lo <= p.grad.data_ptr() < hi for m in (nc, nf) for p in m.parameters())
+    # accumulation without begin() falls back to autograd's in-place add into the same views
+    run()
+    assert torch.allclose(ex.flat, 2 * want, rtol=1e-6, atol=1e-12)
+    # one Adam step from the views equals one from ordinary gradients
+    opt = train.FusedAdam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4)
+    ex.begin()
+    run()
+    ex.finish()
+    opt.step()
+    assert torch.isfinite(nc.alpha_linear.weight).all()

@@ -20,8 +20,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-exchange", action="store_true", help="ordinary autograd gradients instead of the flat buffer")
     args = ap.parse_args()
-    from nerf_loc_amd import helpers, render, synth, train
+    from nerf_loc_amd import dist as ndist, helpers, render, synth, train
     train.set_train_precision(args.precision)
     dev = torch.device("cuda:0")
 
@@ -35,14 +36,15 @@ def main():
     kw = dict(network_query_fn=q, perturb=1.0, N_importance=128, network_fine=nf, N_samples=64, network_fn=nc,
               white_bkgd=True, raw_noise_std=0.0)
     opt = train.FusedAdam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    ex = None if args.no_exchange else ndist.GradientExchange([nc, nf])
     rays = torch.from_numpy(synth.random_rays(args.rays, seed=0)).to(dev)
     target = torch.rand(args.rays, 3, device=dev)
     for i in range(args.warmup):
-        train.train_step(rays, target, kw, opt, i + 1, 5e-4, 500, chunk=1 << 20)
+        train.train_step(rays, target, kw, opt, i + 1, 5e-4, 500, chunk=1 << 20, exchange=ex)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss, _ = train.train_step(rays, target, kw, opt, i + 1, 5e-4, 500, chunk=1 << 20)
+        loss, _ = train.train_step(rays, target, kw, opt, i + 1, 5e-4, 500, chunk=1 << 20, exchange=ex)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     flop = args.rays * 256 * 1186816 * 3.0
