@@ -226,7 +226,7 @@ struct ReduceArgs {
     int N, K;                                             // rows / columns to emit
     float* dst; int ld; int col_off; int map;
     const float* x_scale;
-    const float* bpart; float* db;                        // optional: block row N adds [n_parts][256] into db[N]
+    const float* bpart; float* db; int bstride;           // optional: block row N adds [n_parts][bstride] into db[N]
 };
 // Block: 64 columns x RED_SPLIT slices of the parts.  A thread adds its slice in part order (eight interleaved chains
 // keep eight loads in flight), the slices are combined in slice order through LDS: the order of additions is fixed.
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * RED_SPLIT) void wgrad_reduce_kernel(ReduceArgs
     float sum = 0.f;
     if (on) {
         const float* p = bias_row ? a.bpart + col : a.part + (size_t)row * a.pcol + col;
-        const size_t stride = bias_row ? 256 : (size_t)a.prow * a.pcol;
+        const size_t stride = bias_row ? (size_t)a.bstride : (size_t)a.prow * a.pcol;
         const int per = (a.n_parts + RED_SPLIT - 1) / RED_SPLIT;
         int i = sl * per;
         const int end = i + per < a.n_parts ? i + per : a.n_parts;
@@ -284,7 +284,7 @@ static long long wg_min_chunk() {
 int launch_wgrad_reduce(const float* ws, int parts, int pcol, int pcol0, int n_rows, int k_emit, float* dW, int ld,
                         int col_off, int map, const float* x_scale, float* db, hipStream_t st) {
     ReduceArgs r{ws + pcol0, parts, 256, pcol, n_rows, k_emit, dW, ld, col_off, map, x_scale,
-                 ws + WG_BIAS_OFFSET, db};
+                 ws + WG_BIAS_OFFSET, db, 256};
     const int cols = k_emit > n_rows ? k_emit : n_rows;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cols + 63) / 64, n_rows + (db ? 1 : 0)), dim3(64 * RED_SPLIT), 0, st, r);
     NERF_LAUNCH_CHECK();
@@ -319,14 +319,12 @@ int launch_wgrad(const float* G, int ldg, int N, const float* X, int ldx, int K,
     NERF_LAUNCH_CHECK();
     // N = 128: every slot holds two partial tiles of 128 rows (see the kernel), i.e. 2 x parts tiles of 128 rows
     const int tiles = N == 128 ? 2 * (int)parts : (int)parts, tile_rows = N == 128 ? 128 : 256;
-    ReduceArgs r{ws, tiles, tile_rows, 32 * ctp, N, map == 0 ? K : 32 * ct, dW, ld, col_off, map, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r.K + 63) / 64, N), dim3(64 * RED_SPLIT), 0, st, r);
+    // one launch: block rows 0 .. N - 1 reduce the weight tile, block row N (if db) the column sums of G
+    ReduceArgs r{ws, tiles, tile_rows, 32 * ctp, N, map == 0 ? K : 32 * ct, dW, ld, col_off, map, nullptr,
+                 db ? a.bpart : nullptr, db, tile_rows};
+    const int cols = (db && N > r.K) ? N : r.K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cols + 63) / 64, N + (db ? 1 : 0)), dim3(64 * RED_SPLIT), 0, st, r);
     NERF_LAUNCH_CHECK();
-    if (db) {
-        ReduceArgs rb{a.bpart, tiles, 1, tile_rows, 1, N, db, N, 0, 0, nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N + 63) / 64, 1), dim3(64 * RED_SPLIT), 0, st, rb);
-        NERF_LAUNCH_CHECK();
-    }
     return NERF_OK;
 }
 
@@ -340,11 +338,8 @@ int launch_wgrad_small(const float* d_raw, int ldr, int c0, int N, const float* 
     WsmallArgs a{d_raw, ldr, c0, N, X, K, M, chunk, ws, ws + (size_t)1024 * 8 * 256};
     hipLaunchKernelGGL(wgrad_small_kernel, dim3((unsigned)parts), dim3(K), 0, st, a);
     NERF_LAUNCH_CHECK();
-    ReduceArgs r{ws, (int)parts, 8, K, N, K, dW, K, 0, 0, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K + 63) / 64, N), dim3(64 * RED_SPLIT), 0, st, r);
-    NERF_LAUNCH_CHECK();
-    ReduceArgs rb{a.bpart, (int)parts, 1, 8, 1, N, db, N, 0, 0, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1, 1), dim3(64 * RED_SPLIT), 0, st, rb);
+    ReduceArgs r{ws, (int)parts, 8, K, N, K, dW, K, 0, 0, nullptr, a.bpart, db, 8};      // block row N: the bias
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K + 63) / 64, N + 1), dim3(64 * RED_SPLIT), 0, st, r);
     NERF_LAUNCH_CHECK();
     return NERF_OK;
 }
