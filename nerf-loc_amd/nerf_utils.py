@@ -192,6 +192,9 @@ def render_path_device_objects(render_poses, hwf, K, render_kwargs_list, render_
     near, far = kw.pop('near', 0.), kw.pop('far', 1.)
     use_viewdirs, ndc = kw.pop('use_viewdirs', False), kw.pop('ndc', False)
     O, P = len(render_kwargs_list), len(render_poses[0])
+    if len(render_poses) != O or any(len(p) != P for p in render_poses):
+        raise ValueError("render_path_device_objects: %d objects need %d pose lists of equal length, got lengths %s"
+                         % (O, O, [len(p) for p in render_poses]))
     Ks = K if (isinstance(K, (list, tuple)) and len(K) == O and np.ndim(K[0]) == 2) else [K] * O
     rays = _rays_of_views(H, W, Ks, render_poses, ndc, near, far, use_viewdirs)
     kw['network_fn'] = [k['network_fn'] for k in render_kwargs_list]

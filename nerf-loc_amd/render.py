@@ -154,6 +154,14 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     arguments serve the NeRF-Loc flavour (nerf_utils.py:248-342)."""
     if ray_batch.dim() != 2 or ray_batch.shape[-1] < 8:
         raise ValueError("ray_batch must be [N, 8] or [N, 11], got %s" % (tuple(ray_batch.shape),))
+    if isinstance(network_fn, (list, tuple)):
+        # one network per object: object o owns the o-th equal share of THIS batch, in both passes.  A single fine
+        # network would render every object's rays with the same weights.
+        if network_fine is not None and not (isinstance(network_fine, (list, tuple)) and len(network_fine) == len(network_fn)):
+            raise ValueError("render_rays: with a list of %d coarse networks, network_fine must be None or a list of the "
+                             "same length" % len(network_fn))
+    elif isinstance(network_fine, (list, tuple)):
+        raise ValueError("render_rays: a list of fine networks needs a list of coarse networks of the same length")
     rays = ray_batch if (ray_batch.dtype == torch.float32 and ray_batch.is_contiguous()) else ray_batch.float().contiguous()
     N_rays, cols = rays.shape
     dev = rays.device
@@ -171,7 +179,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     z_vals = hip.z_vals(rays, N_samples, lindisp, t_rand)
 
     fused = isinstance(network_query_fn, NetworkQuery)
-    training = _needs_grad(network_fn) or (network_fine is not None and _needs_grad(network_fine))
+    training = not isinstance(network_fn, (list, tuple)) and (
+        _needs_grad(network_fn) or (network_fine is not None and _needs_grad(network_fine)))
     if training:
         from . import train
         return train.render_rays_autograd(rays, z_vals, network_fn, network_query_fn, N_samples, retraw, perturb,
@@ -270,6 +279,10 @@ def warn_nonfinite(ret, skip=()):
 # ---------------------------------------------------------------------------- run_nerf.py:54-134
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """Render rays in smaller minibatches to bound memory (run_nerf.py:54-66)."""
+    if isinstance(kwargs.get('network_fn'), (list, tuple)) and chunk < rays_flat.shape[0]:
+        # every chunk would be re-split over all the networks: rays of one object rendered with another's weights
+        raise ValueError("batchify_rays: a list of networks shares out the WHOLE ray batch (%d rays); chunk=%d would cut "
+                         "it" % (rays_flat.shape[0], chunk))
     all_ret = {}
     for i in range(0, rays_flat.shape[0], chunk):
         ret = render_rays(rays_flat[i:i + chunk], **kwargs)

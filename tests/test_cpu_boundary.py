@@ -84,6 +84,14 @@ def test_packed_sizes_host_only():
     assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16, 0) == 976 * frag + 65 * bias + scales + rowsums + 976 * frag + 8320
     assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 1) == 2368 * frag + 78 * bias + scales
     assert lib.nerf_mlp_packed_bytes(hip.PREC_F32, 0) == 1952 * frag + 65 * bias + scales
+    # split-operand streams: 3 (2) bf16 terms of each of the 1172 / 968 fragments, padded to whole 16-fragment stages,
+    # then the 16-float bias tiles
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16X3, 1) == 3520 * frag + 9856
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16X3, 0) == 2912 * frag + 8320
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16X2, 1) == 2352 * frag + 9856
+    assert lib.nerf_mlp_packed_bytes(hip.PREC_BF16X2, 0) == 1936 * frag + 8320
+    assert lib.nerf_mlp_packed_bytes(17, 1) == 0
+    assert hip.PRECISIONS["bf16x3"] == hip.PREC_BF16X3 == 2 and hip.PRECISIONS["bf16x2"] == hip.PREC_BF16X2 == 3
 
 
 def test_invalid_arguments_are_refused_before_any_launch():
@@ -307,3 +315,27 @@ def test_c_program_is_built_and_links_the_library():
     assert os.path.exists(binary), "build first: python -c 'import __graft_entry__ as g; g.build()'"
     p = subprocess.run([binary], capture_output=True, text=True, timeout=60)
     assert p.returncode == 1 and "usage: render_c" in p.stderr
+
+
+def test_lists_of_networks_are_checked_before_any_device_work():
+    """One network per object: the whole ray batch is shared out in equal consecutive parts.  What would silently
+    render rays with another object's weights is refused: a single fine network beside a list of coarse ones, a chunk
+    that cuts the batch, pose lists of unequal length."""
+    import torch
+    from nerf_loc_amd import nerf_utils, render
+    rays = torch.zeros(8, 11)
+    q = render.NetworkQuery(None, None, 65536)
+    with pytest.raises(ValueError, match="network_fine must be None or a list"):
+        render.render_rays(rays, [object(), object()], q, 4, N_importance=4, network_fine=object())
+    with pytest.raises(ValueError, match="network_fine must be None or a list"):
+        render.render_rays(rays, [object(), object()], q, 4, N_importance=4, network_fine=[object()])
+    with pytest.raises(ValueError, match="needs a list of coarse networks"):
+        render.render_rays(rays, object(), q, 4, N_importance=4, network_fine=[object(), object()])
+    with pytest.raises(ValueError, match="shares out the WHOLE ray batch"):
+        render.batchify_rays(rays, 4, network_fn=[object(), object()], network_query_fn=q, N_samples=4)
+    kws = [dict(network_fn=object(), near=0.1, far=9.0) for _ in range(3)]
+    eye = torch.eye(4)[:3]
+    with pytest.raises(ValueError, match="pose lists of equal length"):
+        nerf_utils.render_path_device_objects([[eye, eye], [eye], [eye, eye, eye]], [4, 4, 3.0], None, kws)
+    with pytest.raises(ValueError, match="pose lists of equal length"):
+        nerf_utils.render_path_device_objects([[eye], [eye]], [4, 4, 3.0], None, kws)

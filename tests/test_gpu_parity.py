@@ -871,6 +871,23 @@ def test_object_batch_equals_per_object_renders(dev, precision):
             assert torch.equal(got[k][o], one[k]), (o, k)
 
 
+def test_object_batch_with_fine_networks(dev):
+    """Lists of coarse AND fine networks: object o's share of the batch goes through its own pair in both passes,
+    bit-identical to rendering each object by itself."""
+    from nerf_loc_amd import render
+    rays = T(synth.random_rays(192, seed=33), dev)
+    cs = [load_net(synth.make_state_dict(120 + o, "B"), dev) for o in range(3)]
+    fs = [load_net(synth.make_state_dict(130 + o, "B"), dev) for o in range(3)]
+    q = _query(dev)
+    both = render.render_rays(rays, cs, q, 64, retraw=True, N_importance=128, network_fine=fs, white_bkgd=True)
+    for o in range(3):
+        one = render.render_rays(rays[64 * o:64 * (o + 1)], cs[o], q, 64, retraw=True, N_importance=128, network_fine=fs[o],
+                                 white_bkgd=True)
+        for k in ("rgb_map", "acc_map", "rgb0", "raw", "z_std"):
+            assert torch.equal(both[k][64 * o:64 * (o + 1)], one[k]), (o, k)
+    assert float((both["rgb_map"][:64] - both["rgb_map"][64:128]).abs().max()) > 1e-3
+
+
 def test_nonfinite_census(dev):
     from nerf_loc_amd import hip, render
     a = torch.zeros(100003, device=dev)
