@@ -62,11 +62,13 @@ class ObjectBank:
 
     `ckpt_paths` follows load_nerf_model: a list of files of which the last is used, or one path.  `capacity` bounds
     the number of resident objects (least recently used ones are dropped); None keeps everything.  `workers`: reader
-    threads; torch's restricted unpickler is Python code that holds the interpreter lock, so one reader (which
-    overlaps with the caller's copy and packing launches) is as fast as it gets: measured 11.6 ms per 12 MB checkpoint
-    with 1 reader, 23 ms with 4."""
+    threads.  torch's restricted unpickler (`weights_only=True`) is Python code that holds the interpreter lock for
+    nearly all of a read (about 200 tensor records per nerf-pytorch checkpoint; the bytes themselves are memory-mapped),
+    so readers do not run side by side: one reader, which overlaps with the caller's copy and packing launches, is as
+    fast as it gets (measured 11.6 ms per 12 MB checkpoint with 1 reader, 23 ms with 4: the threads take turns on the
+    lock and pay for the hand-overs).  More than one reader is therefore refused unless `allow_slow_readers` is set."""
 
-    def __init__(self, render_kwargs_test, capacity=None, workers=1, precision=None):
+    def __init__(self, render_kwargs_test, capacity=None, workers=1, precision=None, allow_slow_readers=False):
         self.template = dict(render_kwargs_test)
         net = self.template['network_fn']
         if not isinstance(net, NeRF):
@@ -79,7 +81,11 @@ class ObjectBank:
         self._precision = precision if precision is not None else net.precision
         self.layout, self.total = state_dict_layout(net)
         self.capacity = capacity
-        self._pool = ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="nerf-objectbank")
+        workers = max(1, int(workers))
+        if workers > 1 and not allow_slow_readers:
+            workers = 1                                      # see the class docstring: more readers are slower
+        self.workers = workers
+        self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="nerf-objectbank")
         self._pending = {}                                   # key -> Future of (flat, step)
         self._resident = collections.OrderedDict()           # key -> _Entry, least recently used first
         self._lock = threading.Lock()
@@ -99,7 +105,13 @@ class ObjectBank:
         return torch.empty(self.total, dtype=torch.float32, pin_memory=True)
 
     def _read(self, path):
-        return read_flat(path, self.layout, self.total, out=self._staging_get())
+        buf = self._staging_get()
+        try:
+            return read_flat(path, self.layout, self.total, out=buf)
+        except BaseException:
+            with self._lock:
+                self._staging.append(buf)                     # a failed read gives its staging buffer back
+            raise
 
     # ---- reading ahead
     @staticmethod
@@ -166,11 +178,17 @@ class ObjectBank:
                 if e is None:
                     self.request(key, ckpt_paths)
                     with self._lock:
-                        _, fut = self._pending.pop(key)
-                    flat, step = fut.result()
+                        _, fut = self._pending[key]           # stays listed until the object is resident: a request()
+                    try:                                      # from another thread meanwhile must not read it again
+                        flat, step = fut.result()
+                    except BaseException:
+                        with self._lock:
+                            self._pending.pop(key, None)
+                        raise
                     e = self._materialise(key, path, flat, step)
                     with self._lock:
                         self._resident[key] = e
+                        self._pending.pop(key, None)
                         self._resident.move_to_end(key)
                         self.stats['loads'] += 1
                         while self.capacity is not None and len(self._resident) > self.capacity:
@@ -179,9 +197,10 @@ class ObjectBank:
         cur = torch.cuda.current_stream(self.device)
         for t in e.dev:
             t.record_stream(cur)                              # allocated on the side stream, used on this one
-        if e.event is not None:
-            cur.wait_event(e.event)
-            if e.event.query():
+        ev = e.event                                          # read once: another caller may clear it meanwhile
+        if ev is not None:
+            cur.wait_event(ev)
+            if ev.query():
                 e.event = None                                # landed
         return e.net
 

@@ -109,3 +109,30 @@ def test_bank_capacity_and_refusals(dev, tmp_path):
     with pytest.raises(ValueError):
         ObjectBank({**kw_test, 'network_fn': torch.nn.Linear(3, 3)})
     bank.close()
+
+
+def test_failed_read_leaves_the_bank_usable(dev, tmp_path):
+    """A checkpoint of another architecture is refused; its pinned staging buffer goes back to the pool, nothing stays
+    listed as on its way, and the same key loads fine from a good file afterwards.  Reader threads are capped at one
+    (more are slower: the unpickler holds the interpreter lock) unless asked for explicitly."""
+    from nerf_loc_amd import nerf_utils
+    from nerf_loc_amd.objectbank import ObjectBank
+    args = types.SimpleNamespace(nerf_render_rgb=True, nerf_render_depth=True)
+    _, kw_test, _ = nerf_utils.create_nerf_model(args, ckpt_path=None, device=dev, near=0.1, far=9.0)
+    kw_test["network_fn"].requires_grad_(False)
+    assert ObjectBank(kw_test, workers=8).workers == 1
+    assert ObjectBank(kw_test, workers=3, allow_slow_readers=True).workers == 3
+    bank = ObjectBank(kw_test)
+    good, bad = str(tmp_path / "good.tar"), str(tmp_path / "bad.tar")
+    _write_ckpt(good, 410, 5)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(411, "B").items()}
+    sd["alpha_linear.weight"] = torch.zeros(2, 256)
+    torch.save({'global_step': 0, 'network_fn_state_dict': sd}, bad)
+    with pytest.raises(ValueError, match="alpha_linear.weight"):
+        bank.kwargs("k", bad)
+    assert "k" not in bank._pending and "k" not in bank and len(bank._staging) == 1
+    net = bank.kwargs("k", good)["network_fn"]
+    torch.cuda.synchronize()
+    assert bank.global_step("k") == 5 and "k" not in bank._pending
+    assert torch.equal(net.alpha_linear.weight.cpu(), torch.from_numpy(synth.make_state_dict(410, "B")["alpha_linear.weight"]))
+    bank.close()

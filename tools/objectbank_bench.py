@@ -42,8 +42,21 @@ def main():
         torch.cuda.synchronize()
         reload_s = time.perf_counter() - t
         out = {"objects": n_obj, "checkpoint_bytes": size, "reload_per_object_ms": 1e3 * reload_s / n_obj}
-        for workers in (1, 4, 16):
-            bank = ObjectBank(kw, workers=workers)
+        # where a cold load goes: the restricted unpickler alone, on one thread and on four at once (wall time per file)
+        import concurrent.futures as cf
+        from nerf_loc_amd.objectbank import read_flat, state_dict_layout
+        layout, total = state_dict_layout(kw["network_fn"])
+        flat_paths = [p[0] for p in paths]
+        t = time.perf_counter()
+        for p in flat_paths:
+            read_flat(p, layout, total)
+        out["read_flat_1_thread_ms_per_file"] = 1e3 * (time.perf_counter() - t) / n_obj
+        with cf.ThreadPoolExecutor(4) as ex:
+            t = time.perf_counter()
+            list(ex.map(lambda p: read_flat(p, layout, total), flat_paths))
+            out["read_flat_4_threads_ms_per_file"] = 1e3 * (time.perf_counter() - t) / n_obj
+        for workers in (1, 4):
+            bank = ObjectBank(kw, workers=workers, allow_slow_readers=True)
             t = time.perf_counter()
             kws = bank.kwargs_list([(o, paths[o]) for o in range(n_obj)])
             torch.cuda.synchronize()
@@ -60,7 +73,7 @@ def main():
         poses = torch.from_numpy(np.stack([np.concatenate([synth.pose_spherical(45.0 * i, -30.0, 4.0)[:3, :4],
                                                            np.array([[H], [W], [f]], np.float32)], 1) for i in range(8)]))
         n_r = min(n_obj, 8)
-        bank = ObjectBank(kw, workers=4)
+        bank = ObjectBank(kw)
         kws = bank.kwargs_list([(o, paths[o]) for o in range(n_r)])
         pb = poses[None].repeat(n_r, 1, 1, 1).to(dev)
         from nerf_loc_amd import helpers
