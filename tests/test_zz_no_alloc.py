@@ -1,6 +1,7 @@
 """nerf_mlp_backward_static (the entry point for callers that cannot allocate: gradient tape and workspace in the
 library's static device array) against nerf_mlp_backward with caller-provided buffers: identical gradients, bit
-for bit, on two calls in a row, the second with a smaller input; sizes beyond the limit are refused."""
+for bit, on three calls in a row (a smaller input after a larger one, then a larger one again); sizes beyond the limit
+are refused; the call allocates no device memory and can be recorded into a HIP graph and replayed."""
 import numpy as np
 import pytest
 import torch
@@ -38,7 +39,8 @@ def test_static_backward_equals_backward(dev, precision, vd):
     packed = net.packed_weights(prec)
     packed_bwd = hip.mlp_pack_backward([None if p is None else p.detach() for p in params], vd, net.out_channels, precision)
     rs = np.random.RandomState(3)
-    for R, S in ((100, 64), (13, 64)):          # 6400 samples, then 832: the second call reuses the array's contents
+    for R, S in ((100, 64), (13, 64), (120, 64)):      # 6400 samples, then 832, then 7680: every call meets the array as
+                                                       # the previous one left it
         rays = torch.from_numpy(synth.random_rays(R, seed=R)).to(dev)
         if not vd:
             rays = rays[:, :8].contiguous()
@@ -81,3 +83,44 @@ def test_static_backward_refuses_more_than_its_limit(dev):
     want = hip.mlp_backward(packed_bwd, True, 4, d_raw, tape, shapes)
     hip.mlp_backward_static(packed_bwd, True, 4, d_raw, tape, grads)
     assert all(torch.equal(a, b) for a, b in zip(grads, want))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_static_backward_allocates_nothing_and_replays_from_a_graph(dev, precision):
+    """What the entry point exists for: after the first call on the device (which looks the static array's address up)
+    a call neither allocates nor frees device memory (the driver's free-memory figure and torch's allocator stay as they
+    were) and is legal under stream capture: recorded into a HIP graph and replayed on new gradients of the loss, it
+    gives the bits of nerf_mlp_backward."""
+    from nerf_loc_amd import hip, train
+    net = _net(dev, True)
+    params = train._params(net)
+    shapes = [tuple(p.shape) for p in params]
+    prec = hip.PRECISIONS[precision]
+    packed = net.packed_weights(prec)
+    packed_bwd = hip.mlp_pack_backward([p.detach() for p in params], True, 4, precision)
+    R, S = 40, 64
+    rays = torch.from_numpy(synth.random_rays(R, seed=5)).to(dev)
+    z = hip.z_vals(rays, S)
+    raw, tape = hip.mlp_forward_train(packed, True, 4, hip.IN_RAYS, rays, z, R, S, 11, precision=precision)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    d_raw = torch.randn(R * S, 4, device=dev, generator=gen)
+    grads = [torch.zeros(s, device=dev) for s in shapes]
+    hip.mlp_backward_static(packed_bwd, True, 4, d_raw, tape, grads, precision=precision, packed_fwd=packed)   # warm-up
+    torch.cuda.synchronize()
+    free0, alloc0, reserved0 = torch.cuda.mem_get_info(dev)[0], torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)
+    hip.mlp_backward_static(packed_bwd, True, 4, d_raw, tape, grads, precision=precision, packed_fwd=packed)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free0
+    assert torch.cuda.memory_allocated(dev) == alloc0 and torch.cuda.memory_reserved(dev) == reserved0
+    # capture: any allocation, free or synchronising call inside would abort the capture
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        hip.mlp_backward_static(packed_bwd, True, 4, d_raw, tape, grads, precision=precision, packed_fwd=packed)
+    d_raw.copy_(torch.randn(R * S, 4, device=dev, generator=gen))          # new upstream gradients, same buffers
+    for g in grads:
+        g.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    want = hip.mlp_backward(packed_bwd, True, 4, d_raw, tape, shapes, precision=precision, packed_fwd=packed)
+    for i, (a, b) in enumerate(zip(grads, want)):
+        assert torch.equal(a, b), (precision, i, float((a - b).abs().max()))
