@@ -46,8 +46,9 @@ extern "C" {
                               /* in registers, never written to memory (render_rays)               */
 
 /* Version of this interface (2: the training entry points take a `precision` argument; 3: adds
- * nerf_mlp_backward_static; 4: adds nerf_mlp_forward_objects; 5: adds nerf_make_rays_views). */
-#define NERF_HIP_ABI_VERSION 5
+ * nerf_mlp_backward_static; 4: adds nerf_mlp_forward_objects; 5: adds nerf_make_rays_views; 6: the inference entry
+ * points accept NERF_PREC_BF16X3 / NERF_PREC_BF16X2). */
+#define NERF_HIP_ABI_VERSION 6
 int nerf_hip_abi_version(void);
 const char* nerf_last_error(void);
 
@@ -116,7 +117,13 @@ int nerf_mlp_pack(const float* const* tensors_host, int use_viewdirs, int output
  * Domain of NERF_PREC_BF16: network inputs (features, coordinates) of magnitude <= 2^24 (the
  * pack-time activation scales are derived from that bound; beyond it hidden activations may
  * saturate), and the sin/cos features keep bf16 accuracy for |coordinate| up to about 100
- * (fast range reduction).  NERF_PREC_F32 has neither limit.                                 */
+ * (fast range reduction).  NERF_PREC_F32 has neither limit.
+ * NERF_PREC_BF16X3 evaluates the same network with every operand written as a sum of three bf16 numbers and the
+ * six leading products per element, float32 accumulation: results within the float32 kernel's own error of the
+ * reference (measured 1e-6 of the output scale) at about twice its speed; NERF_PREC_BF16X2 (two terms, three
+ * products) is good to 2^-16.  Both take inputs of any magnitude (library sine / cosine, no activation scaling) and
+ * serve nerf_mlp_packed_bytes, nerf_mlp_pack, nerf_mlp_forward and nerf_mlp_forward_objects; the training entry points
+ * take NERF_PREC_F32 or NERF_PREC_BF16 only.                                                  */
 int nerf_mlp_forward(const void* packed, int precision, int use_viewdirs, int output_ch,
                      int input_mode, const float* in0, const float* in1,
                      int R, int S, int ray_cols, float* raw_out, void* stream);

@@ -242,7 +242,11 @@ void mlp_split_kernel(MlpArgs a) {
         RawIn cur_in[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) cur_in[ct] = nxt_in[ct];
+#ifndef NERF_SPX_NOIN      // timing experiment only (results are garbage): what fetching the next pass's inputs costs
         if (!feat_mode && t + tw.stride < tw.end) {
+#else
+        if (false) {
+#endif
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const unsigned m = s0 + (unsigned)(t + tw.stride) * TILE + wave * WSAMP + ct * 16 + c;

@@ -86,9 +86,10 @@ def get_embedder(multires, i=0):
 class NeRF(nn.Module):
     """Same constructor, parameter names and state_dict layout as
     run_nerf_helpers.py:67-94, so nerf-pytorch checkpoints load unchanged.  The
-    forward pass runs the fused MFMA kernel; it supports the architecture the
+    forward pass runs the fused MFMA kernel for the architecture the
     reference's configs use (D=8, W=256, skips=[4], input_ch=63,
-    input_ch_views=27 with view directions, output_ch 4 or 5)."""
+    input_ch_views=27 with view directions, output_ch 4 or 5); other shapes
+    (--netdepth, --netwidth) are evaluated layer by layer with library GEMMs."""
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
         super(NeRF, self).__init__()
@@ -168,10 +169,32 @@ class NeRF(nn.Module):
         (`p.data.mul_(...)`, raw-pointer writes of foreign code); optimizers, `load_state_dict` and `copy_` are seen."""
         self._pack_cache.clear()        # forward streams of both precisions and the training code's transposed ones
 
+    def _forward_library_gemms(self, x):
+        """Any other shape (--netdepth / --netwidth / other skips or encodings, run_nerf.py:440-446): the layers of
+        run_nerf_helpers.py:96-119 as rocBLAS GEMMs through torch.nn.functional, on the GPU the input is on.  No
+        fused kernel exists for these shapes; autograd works through it as for any torch module."""
+        if not x.is_cuda:
+            raise ValueError("NeRF.forward: the input is on %s; this package computes on GPUs only" % x.device)
+        F = torch.nn.functional
+        pts, views = torch.split(x[..., :self.input_ch + self.input_ch_views], [self.input_ch, self.input_ch_views], dim=-1)
+        h = pts
+        for i, lin in enumerate(self.pts_linears):
+            h = F.relu(lin(h))
+            if i in self.skips:
+                h = torch.cat([pts, h], -1)
+        if not self.use_viewdirs:
+            return self.output_linear(h)
+        alpha = self.alpha_linear(h)
+        h = torch.cat([self.feature_linear(h), views], -1)
+        for lin in self.views_linears:
+            h = F.relu(lin(h))
+        return torch.cat([self.rgb_linear(h), alpha], -1)
+
     def forward(self, x):
         """x: [..., input_ch + input_ch_views] encoded features -> [..., 4|output_ch]
         (run_nerf_helpers.py:96-119)."""
-        self._require_supported()
+        if not self.hip_supported():
+            return self._forward_library_gemms(x)
         ch = self.input_ch + (self.input_ch_views if self.use_viewdirs else 0)
         if x.shape[-1] < ch:
             raise ValueError("NeRF.forward expects %d input channels, got %d" % (ch, x.shape[-1]))

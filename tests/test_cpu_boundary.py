@@ -184,8 +184,11 @@ def test_nerf_module_matches_reference_checkpoint_layout():
     novd = helpers.NeRF(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
     assert "output_linear.weight" in novd.state_dict() and novd.out_channels == 5 and novd.hip_supported()
     assert not helpers.NeRF(D=4, W=128, input_ch=63).hip_supported()
-    with torch.no_grad(), pytest.raises(NotImplementedError):
+    # other shapes are evaluated with library GEMMs, on a GPU only: a CPU tensor is refused, not computed
+    with torch.no_grad(), pytest.raises(ValueError, match="computes on GPUs only"):
         helpers.NeRF(D=4, W=128, input_ch=63)(torch.zeros(1, 63))
+    with pytest.raises(NotImplementedError):
+        helpers.NeRF(D=4, W=128, input_ch=63).packed_weights()
 
 
 def test_get_embedder_interface():

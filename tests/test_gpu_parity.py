@@ -313,6 +313,34 @@ def test_mlp_fp32_golden(dev, golden):
     assert maxabs(N(n4(feat[:, :63].contiguous())), ref) < 2e-5 * max(1.0, np.abs(ref).max())
 
 
+def test_other_network_shapes_compose(dev):
+    """--netdepth / --netwidth other than 8 / 256 (run_nerf.py:440-446): no fused kernel, the layers run as library
+    GEMMs; forward against the oracle, a render through the generic path, and gradients through torch's autograd."""
+    from nerf_loc_amd import helpers, render
+    arch = dict(D=4, W=128, skips=(2,))
+    sd = synth.make_state_dict(7, "B", **arch)
+    net = helpers.NeRF(D=4, W=128, input_ch=63, output_ch=4, skips=[2], input_ch_views=27, use_viewdirs=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(dev)
+    assert not net.hip_supported()
+    rs = np.random.RandomState(2)
+    x = rs.uniform(-2, 2, size=(300, 3)).astype(F32)
+    d = rs.normal(size=(300, 3)).astype(F32)
+    feat = np.concatenate([orc.embed(x, 10), orc.embed(d, 4)], -1)
+    ref = orc.mlp_forward(sd, feat, D=4, skips=(2,))
+    with torch.no_grad():
+        out = N(net(T(feat, dev)))
+    assert maxabs(out, ref) < 2e-5 * max(1.0, np.abs(ref).max())
+    rays = synth.random_rays(64, seed=4)
+    with torch.no_grad():
+        r = render.render_rays(T(rays, dev), net, _query(dev), 32, white_bkgd=True)
+    o = orc.render_rays(rays, sd, 32, 0, white_bkgd=True, mlp=lambda s, f, vd: orc.mlp_forward(s, f, vd, D=4, skips=(2,)))
+    assert maxabs(N(r["rgb_map"]), o["rgb_map"]) < 1e-4 and maxabs(N(r["acc_map"]), o["acc_map"]) < 1e-4
+    r = render.render_rays(T(rays, dev), net, _query(dev), 32, white_bkgd=True)
+    r["rgb_map"].sum().backward()
+    assert net.pts_linears[0].weight.grad is not None and float(net.pts_linears[0].weight.grad.abs().max()) > 0
+
+
 def test_mlp_run_network_modes_agree(dev, golden):
     """Features, points and rays input modes of the kernel give the same raw."""
     from nerf_loc_amd import helpers, render, hip
