@@ -47,7 +47,7 @@ extern "C" {
 
 /* Version of this interface (2: the training entry points take a `precision` argument; 3: adds
  * nerf_mlp_backward_static; 4: adds nerf_mlp_forward_objects; 5: adds nerf_make_rays_views; 6: the inference entry
- * points accept NERF_PREC_BF16X3 / NERF_PREC_BF16X2). */
+ * points accept NERF_PREC_BF16X3 / NERF_PREC_BF16X2; adds nerf_render_rays). */
 #define NERF_HIP_ABI_VERSION 6
 int nerf_hip_abi_version(void);
 const char* nerf_last_error(void);
@@ -168,6 +168,41 @@ int nerf_sample_pdf(const float* bins, int bins_stride, int bins_are_z, int nb,
                     const float* z_vals, int n_z,
                     float* z_samples, int32_t* inds, float* z_sorted, float* z_std,
                     void* stream);
+
+/* ---- the whole per-ray pipeline in one call ----------------------------------------------
+ * render_rays (run_nerf.py:314-424; the coarse-only flavour with a depth map: nerf_utils.py:248-342): stratified
+ * depths, coarse network, compositing and, with n_importance > 0, inverse-CDF sampling, the sorted union of depths,
+ * the fine network and the final compositing.  A convenience over the entry points above (it enqueues exactly their
+ * kernels, in the reference's order, on `stream`; results are bit-identical to calling them one by one), for callers
+ * that want one call per ray batch.  All pointers are device pointers; the caller owns every buffer; optional
+ * outputs may be NULL.  rays [R, ray_cols] as render() packs them (run_nerf.py:116-123).                       */
+typedef struct {
+    int n_samples;          /* S: coarse samples per ray                                                      */
+    int n_importance;       /* extra samples of the fine pass, 0 = coarse pass only                           */
+    int precision;          /* NERF_PREC_* of both networks                                                   */
+    int use_viewdirs;       /* rays then have 11 columns and the networks their view branch                   */
+    int output_ch;          /* 4, or 5 without view directions                                                */
+    int ray_cols;           /* row stride of rays, >= 8 (11 with view directions)                             */
+    int lindisp;            /* depths linear in disparity                                                     */
+    int white_bkgd;
+    int u_per_ray;          /* u is [R, n_importance] instead of [n_importance]                               */
+    const float* t_vals;    /* [S] = linspace(0, 1, S) as the host's torch computes it                        */
+    const float* t_rand;    /* [R, S] uniform variates for the stratified jitter, or NULL (perturb = 0)       */
+    const float* u;         /* inverse-CDF variates (n_importance > 0)                                        */
+    const float* noise0;    /* [R, S] scaled density noise of the coarse pass, or NULL                        */
+    const float* noise1;    /* [R, S + n_importance] of the fine pass, or NULL                                */
+} nerf_render_cfg;
+typedef struct {
+    float *rgb, *disp, *acc, *depth;      /* maps of the last pass: [R,3], [R], [R], [R]; rgb required        */
+    float *rgb0, *disp0, *acc0;           /* coarse-pass maps when n_importance > 0                           */
+    float *z_std;                         /* [R] standard deviation of the importance samples                 */
+    float *raw;                           /* [R, S + n_importance, output_ch]: the last pass's network output  */
+    float *z_vals;                        /* [R, S + n_importance]: the last pass's depths                     */
+    float *z_coarse, *raw_coarse;         /* n_importance > 0: [R, S], [R, S, output_ch] work buffers          */
+    float *weights;                       /* [R, S] coarse weights: required when n_importance > 0, else optional */
+} nerf_render_buffers;
+int nerf_render_rays(const void* packed_coarse, const void* packed_fine_or_null, const float* rays, int R,
+                     const nerf_render_cfg* cfg, const nerf_render_buffers* buf, void* stream);
 
 /* ---- training ---------------------------------------------------------------------------
  * The reference trains through PyTorch autograd (run_nerf.py:770-796: render -> img2mse ->

@@ -24,7 +24,22 @@ PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PR
 
 _c_float_p = ctypes.c_void_p   # device pointers travel as integers
 
+class RenderCfg(ctypes.Structure):
+    """nerf_render_cfg of include/nerf_hip.h"""
+    _fields_ = [(n, ctypes.c_int) for n in ("n_samples", "n_importance", "precision", "use_viewdirs", "output_ch", "ray_cols",
+                                            "lindisp", "white_bkgd", "u_per_ray")] + \
+               [(n, ctypes.c_void_p) for n in ("t_vals", "t_rand", "u", "noise0", "noise1")]
+
+
+class RenderBuffers(ctypes.Structure):
+    """nerf_render_buffers of include/nerf_hip.h"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("rgb", "disp", "acc", "depth", "rgb0", "disp0", "acc0", "z_std", "raw", "z_vals",
+                                               "z_coarse", "raw_coarse", "weights")]
+
+
 _SIGNATURES = {
+    "nerf_render_rays": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, ctypes.c_int, ctypes.POINTER(RenderCfg),
+                                        ctypes.POINTER(RenderBuffers), ctypes.c_void_p]),
     "nerf_hip_abi_version": (ctypes.c_int, []),
     "nerf_last_error": (ctypes.c_char_p, []),
     "nerf_selftest_mfma": (ctypes.c_int, []),
@@ -419,6 +434,66 @@ def sample_pdf(bins, weights, u, bins_are_z=False, z_vals=None, want_samples=Tru
                                      n_z, _ptr(zs), None if inds is None else ctypes.c_void_p(inds.data_ptr()),
                                      _ptr(zsorted), _ptr(std), _stream(bins)), "nerf_sample_pdf")
     return zs, inds, zsorted, std
+
+
+def render_rays_fused(packed_coarse, packed_fine, rays, n_samples, n_importance, precision, use_viewdirs, output_ch,
+                      t_vals, u=None, t_rand=None, noise0=None, noise1=None, lindisp=False, white_bkgd=False,
+                      want_weights=False):
+    """nerf_render_rays: the whole of render_rays (run_nerf.py:314-424) as one library call on rays [R, 8|11].
+    Returns the reference's dict (rgb_map, disp_map, acc_map, depth_map, raw, z_vals and, with n_importance > 0, rgb0,
+    disp0, acc0, z_std; weights of the coarse pass on request).  Same kernels, same bits as the calls one by one."""
+    rays = _f32(rays, "rays")
+    dev = rays.device
+    R, cols = rays.shape
+    S, NI = int(n_samples), int(n_importance)
+    _need(cols >= (11 if use_viewdirs else 8), "render_rays_fused: rays need %d columns, got %d", 11 if use_viewdirs else 8, cols)
+    t_vals = _f32(t_vals, "t_vals", dev)
+    _need(t_vals.numel() == S, "render_rays_fused: t_vals must have %d entries", S)
+    need_bytes = lib().nerf_mlp_packed_bytes(int(precision), int(bool(use_viewdirs)))
+    for name, pk in (("packed_coarse", packed_coarse), ("packed_fine", packed_fine)):
+        _need(pk is None or (pk.is_cuda and pk.device == dev and need_bytes > 0 and pk.numel() * pk.element_size() >= need_bytes),
+              "render_rays_fused: %s is not a packed network of this precision on %s", name, dev)
+    _need(packed_coarse is not None, "render_rays_fused: packed_coarse is missing")
+    opt = lambda t, name, shape: None if t is None else _shaped(_f32(t, name, dev), name, shape)
+    t_rand = opt(t_rand, "t_rand", (R, S))
+    noise0 = opt(noise0, "noise0", (R, S))
+    noise1 = opt(noise1, "noise1", (R, S + NI))
+    per_ray = 0
+    if NI > 0:
+        _need(u is not None and S >= 3, "render_rays_fused: importance sampling needs u and at least 3 coarse samples")
+        u = _f32(u, "u", dev)
+        per_ray = int(u.dim() == 2)
+        _need(tuple(u.shape) == ((R, NI) if per_ray else (NI,)), "render_rays_fused: u must be [%d] or [%d, %d]", NI, R, NI)
+    f = dict(dtype=torch.float32, device=dev)
+    ST = S + NI
+    out = {"rgb_map": torch.empty((R, 3), **f), "disp_map": torch.empty((R,), **f), "acc_map": torch.empty((R,), **f),
+           "depth_map": torch.empty((R,), **f), "raw": torch.empty((R, ST, output_ch), **f), "z_vals": torch.empty((R, ST), **f)}
+    work = {}
+    if NI > 0:
+        out.update(rgb0=torch.empty((R, 3), **f), disp0=torch.empty((R,), **f), acc0=torch.empty((R,), **f),
+                   z_std=torch.empty((R,), **f))
+        work = {"z_coarse": torch.empty((R, S), **f), "raw_coarse": torch.empty((R, S, output_ch), **f)}
+    if NI > 0 or want_weights:
+        work["weights"] = torch.empty((R, S), **f)
+    p = lambda t: None if t is None else t.data_ptr()
+    cfg = RenderCfg(S, NI, int(precision), int(bool(use_viewdirs)), int(output_ch), int(cols), int(bool(lindisp)),
+                    int(bool(white_bkgd)), per_ray, p(t_vals), p(t_rand), p(u), p(noise0), p(noise1))
+    buf = RenderBuffers(p(out["rgb_map"]), p(out["disp_map"]), p(out["acc_map"]), p(out["depth_map"]), p(out.get("rgb0")),
+                        p(out.get("disp0")), p(out.get("acc0")), p(out.get("z_std")), p(out["raw"]), p(out["z_vals"]),
+                        p(work.get("z_coarse")), p(work.get("raw_coarse")), p(work.get("weights")))
+    with torch.cuda.device(dev):
+        _check(lib().nerf_render_rays(ctypes.c_void_p(packed_coarse.data_ptr()),
+                                      None if packed_fine is None else ctypes.c_void_p(packed_fine.data_ptr()), _ptr(rays), R,
+                                      ctypes.byref(cfg), ctypes.byref(buf), _stream(rays)), "nerf_render_rays")
+    if want_weights:
+        out["weights0" if NI > 0 else "weights"] = work["weights"]
+    out["_work"] = work          # the launches read and write these asynchronously: keep them alive with the result
+    return out
+
+
+def _shaped(t, name, shape):
+    _need(tuple(t.shape) == tuple(shape), "render_rays_fused: %s must be %s, got %s", name, tuple(shape), tuple(t.shape))
+    return t
 
 
 # --------------------------------------------------------------------------- training

@@ -142,27 +142,31 @@ def test_split_network_input_modes_agree(dev, golden):
     assert maxabs(raw_rays, ref) < 2e-5 * scale
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x2"])
 @pytest.mark.parametrize("regime", ["A", "B"])
-def test_render_bf16x3_vs_reference_golden(dev, golden, regime):
+def test_render_bf16x3_vs_reference_golden(dev, golden, regime, prec):
     """The float32 contract (every map within 1e-4 absolute of the reference's render_rays, g5, free-running: importance
-    samples from the kernel's own coarse weights) in the bf16x3 mode."""
+    samples from the kernel's own coarse weights) in the bf16x3 mode.  bf16x2 (operands good to 2^-16) is NOT a float32
+    substitute: measured rgb 6.1e-5 and disp 1.2e-4 on the trained-like weights, so its bar here is 3e-4."""
+    bar = {"bf16x3": 1e-4, "bf16x2": 3e-4}[prec]
     from nerf_loc_amd import render
     g = golden("g5_render_rays")
     rays = g["rays"]
-    nc = load_net(synth.make_state_dict(50, regime), dev, precision="bf16x3")
-    nf = load_net(synth.make_state_dict(51, regime), dev, precision="bf16x3")
+    nc = load_net(synth.make_state_dict(50, regime), dev, precision=prec)
+    nf = load_net(synth.make_state_dict(51, regime), dev, precision=prec)
     r = render.render_rays(T(rays, dev), nc, _query(dev), 64, retraw=True, N_importance=128, network_fine=nf, white_bkgd=True)
     r = {k: N(v) for k, v in r.items()}
     tag = "cf_" + regime
     assert (np.abs(g["cf64_%s_rawlast" % regime]) > 1e-4).all()      # no ray of the fixture needs masking
     for k in ("rgb0", "acc0", "disp0", "rgb_map", "acc_map", "disp_map"):
         e = maxabs(r[k], g["%s_%s" % (tag, k)])
-        print("  bf16x3 regime %s %s max abs err %.3e" % (regime, k, e))
-        assert e < 1e-4, k
-    assert maxabs(r["z_std"], g[tag + "_z_std"]) < 2e-4
+        print("  %s regime %s %s max abs err %.3e" % (prec, regime, k, e))
+        assert e < bar, (prec, k)
+    assert maxabs(r["z_std"], g[tag + "_z_std"]) < 2 * bar
 
 
-def test_bf16x3_view_rays_and_loc_image(dev, golden):
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x2"])
+def test_bf16x3_view_rays_and_loc_image(dev, golden, prec):
     """4096 pixels of the benchmark's 800 x 800 view (g12) and NeRF-Loc's render() of a 240 x 180 view (g13), both
     rendered by the reference: the bf16x3 mode inside the float32 bars (1e-4 on every map, rays within 1e-4 of the ReLU
     kink at the last sample masked by the reference's float64 run and counted)."""
@@ -170,15 +174,15 @@ def test_bf16x3_view_rays_and_loc_image(dev, golden):
     from nerf_loc_amd import nerf_utils, render
     g = golden("g12_view_rays")
     rays, rawlast = g["rays"], g["f64_rawlast"]
-    nc = load_net(synth.make_state_dict(0, "B"), dev, precision="bf16x3")
-    nf = load_net(synth.make_state_dict(1, "B"), dev, precision="bf16x3")
+    nc = load_net(synth.make_state_dict(0, "B"), dev, precision=prec)
+    nf = load_net(synth.make_state_dict(1, "B"), dev, precision=prec)
     r = render.render_rays(T(rays, dev), nc, _query(dev), 64, N_importance=128, network_fine=nf, white_bkgd=True)
     r = {k: N(v) for k, v in r.items()}
     cond = np.abs(rawlast) > 1e-4
     assert (~cond).sum() <= 8
     for k in ("rgb_map", "acc_map", "rgb0", "acc0"):
         e = np.abs(r[k] - g["f32_" + k]).reshape(len(rays), -1).max(-1)[cond].max()
-        print("  bf16x3 view rays %s max abs err %.2e" % (k, e))
+        print("  %s view rays %s max abs err %.2e" % (prec, k, e))
         assert e < 1e-4, k
     assert np.abs(r["z_std"] - g["f32_z_std"])[cond].max() < 2e-4
     g = golden("g13_loc_image")
@@ -188,7 +192,7 @@ def test_bf16x3_view_rays_and_loc_image(dev, golden):
     _, kw, _ = nerf_utils.create_nerf_model(args, ckpt_path=None, device=dev, near=0.1, far=9.0)
     kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(100, "B").items()})
     kw["network_fn"].requires_grad_(False)
-    kw["network_fn"].precision = "bf16x3"
+    kw["network_fn"].precision = prec
     rgb, disp, acc, depth, _ = nerf_utils.render(H, W, g["K"], chunk=1024 * 32, c2w=T(g["c2w"], dev), **kw)
     pick = lambda v: N(v).reshape(H * W, -1)[idx]
     cond = np.abs(g["raw_sigma_last"]) > 1e-4
@@ -196,7 +200,7 @@ def test_bf16x3_view_rays_and_loc_image(dev, golden):
     e_rgb = np.abs(pick(rgb) - g["rgb"]).max(-1)[cond].max()
     e_acc = np.abs(pick(acc)[:, 0] - g["acc"])[cond].max()
     e_depth = np.abs(pick(depth)[:, 0] - g["depth"])[cond].max()
-    print("  bf16x3 NeRF-Loc 240x180: rgb %.2e acc %.2e depth %.2e" % (e_rgb, e_acc, e_depth))
+    print("  %s NeRF-Loc 240x180: rgb %.2e acc %.2e depth %.2e" % (prec, e_rgb, e_acc, e_depth))
     assert e_rgb < 1e-4 and e_acc < 1e-4 and e_depth < 1e-4
 
 

@@ -2,7 +2,9 @@
 // neither Python nor torch: what a C/C++ serving loop would do with include/nerf_hip.h (render -> render_rays of
 // run_nerf.py:69-134, 314-424 as seven library calls on one HIP stream).
 //
-//   render_c <input file> <output file> direct|graph [timing repetitions]
+//   render_c <input file> <output file> direct|graph|onecall [timing repetitions]
+//
+// "onecall": ray generation, then nerf_render_rays: the other six calls as one.
 //
 // "graph": the seven calls are recorded once with hipStreamBeginCapture and replayed with hipGraphLaunch; no entry
 // point on this path allocates or synchronises, so the sequence is capturable as it stands.  With repetitions > 0 the
@@ -79,11 +81,23 @@ struct Frame {          // everything one render reads and writes, all device me
     Network coarse, fine;
 };
 
+static bool g_onecall = false;
+
 // render() + render_rays() of the reference as library calls, all asynchronous on `st`
 static int enqueue(const Frame& f, hipStream_t st) {
     const int N = f.H * f.W, S = f.S, SA = f.S + f.NI;
     NERF_OK_OR_DIE(nerf_make_rays(N, f.H, f.W, nullptr, nullptr, f.c2w, nullptr, f.fx, f.fy, f.cx, f.cy, f.near, f.far,
                                   nullptr, nullptr, 1, 0, f.fx, 1.0f, f.rays, st));
+    if (g_onecall) {
+        nerf_render_cfg cfg{};
+        cfg.n_samples = S; cfg.n_importance = f.NI; cfg.precision = f.precision; cfg.use_viewdirs = 1; cfg.output_ch = 4;
+        cfg.ray_cols = 11; cfg.white_bkgd = f.white; cfg.t_vals = f.t_vals; cfg.u = f.u;
+        nerf_render_buffers b{};
+        b.rgb = f.rgb; b.disp = f.disp; b.acc = f.acc; b.depth = f.depth; b.rgb0 = f.rgb0; b.disp0 = f.disp0; b.acc0 = f.acc0;
+        b.z_std = f.z_std; b.raw = f.raw_all; b.z_vals = f.z_all; b.z_coarse = f.z; b.raw_coarse = f.raw; b.weights = f.weights;
+        NERF_OK_OR_DIE(nerf_render_rays(f.coarse.packed, f.fine.packed, f.rays, N, &cfg, &b, st));
+        return 0;
+    }
     NERF_OK_OR_DIE(nerf_z_vals(f.rays, 11, N, S, f.t_vals, nullptr, 0, f.z, st));
     NERF_OK_OR_DIE(nerf_mlp_forward(f.coarse.packed, f.precision, 1, 4, NERF_IN_RAYS, f.rays, f.z, N, S, 11, f.raw, st));
     NERF_OK_OR_DIE(nerf_raw2outputs(f.raw, 4, f.z, f.rays + 3, 11, nullptr, N, S, f.white, f.rgb0, f.disp0, f.acc0, f.depth,
@@ -98,10 +112,11 @@ static int enqueue(const Frame& f, hipStream_t st) {
 
 int main(int argc, char** argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: render_c <input> <output> direct|graph [timing repetitions]\n");
+        fprintf(stderr, "usage: render_c <input> <output> direct|graph|onecall [timing repetitions]\n");
         return 1;
     }
     const bool use_graph = strcmp(argv[3], "graph") == 0;
+    g_onecall = strcmp(argv[3], "onecall") == 0;
     const int reps = argc > 4 ? atoi(argv[4]) : 0;
     if (nerf_hip_abi_version() != NERF_HIP_ABI_VERSION) {
         fprintf(stderr, "render_c: library ABI %d, header %d\n", nerf_hip_abi_version(), NERF_HIP_ABI_VERSION);
