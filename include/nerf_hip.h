@@ -47,7 +47,7 @@ extern "C" {
 
 /* Version of this interface (2: the training entry points take a `precision` argument; 3: adds
  * nerf_mlp_backward_static; 4: adds nerf_mlp_forward_objects; 5: adds nerf_make_rays_views; 6: the inference entry
- * points accept NERF_PREC_BF16X3 / NERF_PREC_BF16X2; adds nerf_render_rays). */
+ * points accept NERF_PREC_BF16X3 / NERF_PREC_BF16X2; adds nerf_render_rays; nerf_raw2outputs_backward takes g_weights). */
 #define NERF_HIP_ABI_VERSION 6
 int nerf_hip_abi_version(void);
 const char* nerf_last_error(void);
@@ -214,12 +214,13 @@ int nerf_render_rays(const void* packed_coarse, const void* packed_fine_or_null,
  * streams and entry points of one training step must all use the same precision.
  *
  * nerf_raw2outputs_backward: backward of raw2outputs (run_nerf.py:268-311).  g_rgb [R,3], g_disp,
- * g_acc, g_depth [R] are the upstream gradients of the maps (any may be NULL = zero); d_raw
- * [R,S,raw_ch] receives dL/draw.  S <= 256.  No gradient flows to z_vals or rays_d.          */
+ * g_acc, g_depth [R] and g_weights [R,S] are the upstream gradients of the maps and of the
+ * per-sample weights (any may be NULL = zero); d_raw [R,S,raw_ch] receives dL/draw.  S <= 256.
+ * No gradient flows to z_vals or rays_d.                                                      */
 int nerf_raw2outputs_backward(const float* raw, int raw_ch, const float* z_vals, const float* d_ptr,
                               int d_stride, const float* noise, int R, int S, int white_bkgd,
                               const float* g_rgb, const float* g_disp, const float* g_acc,
-                              const float* g_depth, float* d_raw, void* stream);
+                              const float* g_depth, const float* g_weights, float* d_raw, void* stream);
 
 /* Buffers the caller owns: the activation tape written by the training forward and read by
  * the backward, the gradient tape (scratch of the backward), and a fixed-size workspace.     */

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void raw2outputs_bwd_kernel(
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ d_ptr, int d_stride,
     const float* __restrict__ noise, int R, int S, int white_bkgd, const float* __restrict__ g_rgb,
     const float* __restrict__ g_disp, const float* __restrict__ g_acc, const float* __restrict__ g_depth,
-    float* __restrict__ d_raw) {
+    const float* __restrict__ g_weights, float* __restrict__ d_raw) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= R) return;
@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void raw2outputs_bwd_kernel(
         const int i = 64 * k + lane;
         const bool valid = i < S;
         const float w = alpha[k] * T[k];
-        const float q = g0 * c0[k] + g1 * c1[k] + g2 * c2[k] - bgterm + ga + gd * z[k];
+        float q = g0 * c0[k] + g1 * c1[k] + g2 * c2[k] - bgterm + ga + gd * z[k];
+        if (g_weights && valid) q += g_weights[(size_t)ray * S + i];      // a loss on the weights themselves
         const float term = valid ? q * w : 0.0f;
         float incl = term;                    // inclusive suffix sum within the chunk
 #pragma unroll
@@ -433,10 +434,11 @@ extern "C" int nerf_raw2outputs(const float* raw, int raw_ch, const float* z_val
 template <int RAW_CH>
 static void launch_r2o_bwd(int nch, dim3 grid, dim3 block, hipStream_t st, const float* raw, const float* z,
                            const float* d_ptr, int d_stride, const float* noise, int R, int S, int white,
-                           const float* g_rgb, const float* g_disp, const float* g_acc, const float* g_depth, float* d_raw) {
+                           const float* g_rgb, const float* g_disp, const float* g_acc, const float* g_depth,
+                           const float* g_weights, float* d_raw) {
 #define NERF_R2O_CASE(n)                                                                                           \
     case n: hipLaunchKernelGGL((raw2outputs_bwd_kernel<RAW_CH, n>), grid, block, 0, st, raw, z, d_ptr, d_stride,   \
-                               noise, R, S, white, g_rgb, g_disp, g_acc, g_depth, d_raw); break;
+                               noise, R, S, white, g_rgb, g_disp, g_acc, g_depth, g_weights, d_raw); break;
     switch (nch) { NERF_R2O_CASE(1) NERF_R2O_CASE(2) NERF_R2O_CASE(3) default: NERF_R2O_CASE(4) }
 #undef NERF_R2O_CASE
 }
@@ -444,7 +446,7 @@ static void launch_r2o_bwd(int nch, dim3 grid, dim3 block, hipStream_t st, const
 extern "C" int nerf_raw2outputs_backward(const float* raw, int raw_ch, const float* z_vals, const float* d_ptr,
                                          int d_stride, const float* noise, int R, int S, int white_bkgd,
                                          const float* g_rgb, const float* g_disp, const float* g_acc,
-                                         const float* g_depth, float* d_raw, void* stream) {
+                                         const float* g_depth, const float* g_weights, float* d_raw, void* stream) {
     NERF_REQUIRE(R == 0 || (raw && z_vals && d_ptr && d_raw), "nerf_raw2outputs_backward: null pointer");
     NERF_REQUIRE(raw_ch == 4 || raw_ch == 5, "nerf_raw2outputs_backward: raw_ch must be 4 or 5, got %d", raw_ch);
     NERF_REQUIRE(R >= 0 && S >= 1 && d_stride >= 3, "nerf_raw2outputs_backward: bad shape R=%d S=%d d_stride=%d", R, S, d_stride);
@@ -461,9 +463,9 @@ extern "C" int nerf_raw2outputs_backward(const float* raw, int raw_ch, const flo
     dim3 grid((R + 3) / 4), block(4 * WAVE);
     const int nch = (S + 63) / 64;
     if (raw_ch == 4) launch_r2o_bwd<4>(nch, grid, block, as_stream(stream), raw, z_vals, d_ptr, d_stride, noise, R, S,
-                                       white_bkgd, g_rgb, g_disp, g_acc, g_depth, d_raw);
+                                       white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, d_raw);
     else launch_r2o_bwd<5>(nch, grid, block, as_stream(stream), raw, z_vals, d_ptr, d_stride, noise, R, S, white_bkgd,
-                           g_rgb, g_disp, g_acc, g_depth, d_raw);
+                           g_rgb, g_disp, g_acc, g_depth, g_weights, d_raw);
     NERF_LAUNCH_CHECK();
     return NERF_OK;
 }

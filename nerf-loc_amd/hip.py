@@ -73,7 +73,7 @@ _SIGNATURES = {
                                        _c_float_p, ctypes.c_void_p]),
     "nerf_raw2outputs_backward": (ctypes.c_int, [_c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int,
                                                  _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p,
-                                                 _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
+                                                 _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "nerf_train_tape_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
     "nerf_train_grad_tape_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
     "nerf_train_workspace_bytes": (ctypes.c_size_t, []),
@@ -497,14 +497,15 @@ def _shaped(t, name, shape):
 
 
 # --------------------------------------------------------------------------- training
-def raw2outputs_backward(raw, z, d, d_stride, noise, white_bkgd, g_rgb=None, g_disp=None, g_acc=None, g_depth=None):
-    """dL/draw [R,S,ch] from the upstream gradients of the maps (None = zero)."""
+def raw2outputs_backward(raw, z, d, d_stride, noise, white_bkgd, g_rgb=None, g_disp=None, g_acc=None, g_depth=None,
+                         g_weights=None):
+    """dL/draw [R,S,ch] from the upstream gradients of the maps and of the per-sample weights [R,S] (None = zero)."""
     raw, z = _f32(raw, "raw"), _f32(z, "z_vals", raw.device)
     R, S, ch = raw.shape
     dev = raw.device
     _need(tuple(z.shape) == (R, S), "raw2outputs_backward: z_vals %s does not match raw %s", tuple(z.shape), tuple(raw.shape))
-    gs = [None if g is None else _f32(g, "upstream gradient", dev) for g in (g_rgb, g_disp, g_acc, g_depth)]
-    for g, n_el in zip(gs, (3 * R, R, R, R)):
+    gs = [None if g is None else _f32(g, "upstream gradient", dev) for g in (g_rgb, g_disp, g_acc, g_depth, g_weights)]
+    for g, n_el in zip(gs, (3 * R, R, R, R, R * S)):
         _need(g is None or g.numel() == n_el, "raw2outputs_backward: an upstream gradient holds %d values, %d expected",
               0 if g is None else g.numel(), n_el)
     noise = _f32(noise, "noise", dev) if noise is not None else None
@@ -513,7 +514,7 @@ def raw2outputs_backward(raw, z, d, d_stride, noise, white_bkgd, g_rgb=None, g_d
     with torch.cuda.device(dev):
         _check(lib().nerf_raw2outputs_backward(_ptr(raw), ch, _ptr(z), _dir_ptr(d, dev, R, int(d_stride)), int(d_stride),
                                                _ptr(noise), R, S, int(bool(white_bkgd)), _ptr(gs[0]), _ptr(gs[1]),
-                                               _ptr(gs[2]), _ptr(gs[3]), _ptr(d_raw), _stream(raw)),
+                                               _ptr(gs[2]), _ptr(gs[3]), _ptr(gs[4]), _ptr(d_raw), _stream(raw)),
                "nerf_raw2outputs_backward")
     return d_raw
 

@@ -130,14 +130,14 @@ class _CompositeFn(torch.autograd.Function):
         ctx.save_for_backward(raw, z_vals, d)
         ctx.misc = (d_stride, noise, white_bkgd)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(weights)
         return rgb, disp, acc, weights, depth
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_weights, g_depth):
         raw, z_vals, d = ctx.saved_tensors
         d_stride, noise, white_bkgd = ctx.misc
-        d_raw = hip.raw2outputs_backward(raw, z_vals, d, d_stride, noise, white_bkgd, g_rgb, g_disp, g_acc, g_depth)
+        d_raw = hip.raw2outputs_backward(raw, z_vals, d, d_stride, noise, white_bkgd, g_rgb, g_disp, g_acc, g_depth,
+                                         None if g_weights is None else g_weights.contiguous())
         return d_raw, None, None, None, None, None
 
 

@@ -352,7 +352,7 @@ def render_rays(rays, sd_coarse, N_samples, N_importance=0, sd_fine=None, use_vi
 # run_nerf_helpers.py:96-119 with autograd; run_nerf.py:776-785 is the loss)
 # --------------------------------------------------------------------------
 def raw2outputs_backward(raw, z_vals, rays_d, noise=None, white_bkgd=False, g_rgb=None, g_disp=None, g_acc=None,
-                         g_depth=None):
+                         g_depth=None, g_weights=None):
     """dL/draw [R,S,C] for upstream gradients of the maps, in float64 closed form (what autograd yields for
     raw2outputs): c = sigmoid(raw_rgb), e = exp(-relu(sigma) dist), T = exclusive cumprod(e + 1e-10), w = (1-e) T."""
     R, S, C = raw.shape
@@ -381,6 +381,8 @@ def raw2outputs_backward(raw, z_vals, rays_d, noise=None, white_bkgd=False, g_rg
             gd = gd + np.where(live, g_disp * (-disp * disp / acc), 0.0)
             ga = ga + np.where(live, g_disp * (disp * disp * depth / (acc * acc)), 0.0)
     qw = (c * g_rgb[:, None, :]).sum(-1) - (g_rgb.sum(-1)[:, None] if white_bkgd else 0.0) + ga[:, None] + gd[:, None] * z
+    if g_weights is not None:              # a loss on the weights themselves (run_nerf.py:303 returns them)
+        qw = qw + g_weights.astype(f)
     term = qw * w
     suffix = np.cumsum(term[:, ::-1], -1)[:, ::-1] - term          # sum over later samples
     dalpha = qw * T - suffix / one_m

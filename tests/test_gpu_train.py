@@ -60,12 +60,13 @@ def test_raw2outputs_backward(dev, S, white, with_noise):
     noise = rs.randn(R, S).astype(F32) if with_noise else None
     g_rgb = rs.randn(R, 3).astype(F32)
     g_acc, g_depth, g_disp = rs.randn(R).astype(F32), rs.randn(R).astype(F32), rs.randn(R).astype(F32)
+    g_w = rs.randn(R, S).astype(F32)
     g_disp[::7] = 0.0                                              # disp is NaN there; autograd would give NaN too
     dt = T(d, dev)
     for extra in (False, True):
         kw = dict(g_rgb=g_rgb)
         if extra:
-            kw.update(g_acc=g_acc, g_depth=g_depth, g_disp=g_disp)
+            kw.update(g_acc=g_acc, g_depth=g_depth, g_disp=g_disp, g_weights=g_w)
         ref = orc.raw2outputs_backward(raw, z, d, noise, white, **kw)
         got = hip.raw2outputs_backward(T(raw, dev), T(z, dev), dt, 3, None if noise is None else T(noise, dev), white,
                                        **{k: T(v, dev) for k, v in kw.items()})
@@ -85,8 +86,8 @@ def test_raw2outputs_autograd_matches_torch(dev):
     tgt = rs.uniform(size=(R, 3)).astype(F32)
     rt = T(raw, dev).requires_grad_(True)
     rgb, disp, acc, w, depth = render.raw2outputs(rt, T(z, dev), T(d, dev), 0, True)
-    assert not w.requires_grad
-    loss = ((rgb - T(tgt, dev)) ** 2).mean() + 0.1 * acc.mean() + 0.01 * depth.mean()
+    assert w.requires_grad            # a regulariser on the weights (e.g. their entropy) is differentiated too
+    loss = ((rgb - T(tgt, dev)) ** 2).mean() + 0.1 * acc.mean() + 0.01 * depth.mean() + 0.05 * (w ** 2).sum(-1).mean()
     loss.backward()
     r64 = torch.tensor(raw, dtype=torch.float64, requires_grad=True)
     z64, d64 = torch.tensor(z, dtype=torch.float64), torch.tensor(d, dtype=torch.float64)
@@ -95,7 +96,8 @@ def test_raw2outputs_autograd_matches_torch(dev):
     Tr = torch.cumprod(torch.cat([torch.ones(R, 1, dtype=torch.float64), 1 - alpha + 1e-10], -1), -1)[:, :-1]
     w64 = alpha * Tr
     rgb64 = (w64[..., None] * torch.sigmoid(r64[..., :3])).sum(-2) + (1 - w64.sum(-1, keepdim=True))
-    l64 = ((rgb64 - torch.tensor(tgt, dtype=torch.float64)) ** 2).mean() + 0.1 * w64.sum(-1).mean() + 0.01 * (w64 * z64).sum(-1).mean()
+    l64 = (((rgb64 - torch.tensor(tgt, dtype=torch.float64)) ** 2).mean() + 0.1 * w64.sum(-1).mean() +
+           0.01 * (w64 * z64).sum(-1).mean() + 0.05 * (w64 ** 2).sum(-1).mean())
     l64.backward()
     assert abs(float(loss.detach()) - float(l64.detach())) < 1e-6
     assert relerr(N(rt.grad), r64.grad.numpy()) < 2e-4
