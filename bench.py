@@ -153,7 +153,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x2"])
-    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
                     help="train workload only: float32 (what the reference computes) or bf16 MFMA operands")
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--chunk", type=int, default=1 << 20)
@@ -329,8 +329,8 @@ def make_workload(name, precision, args, rank, world, device):
                                                       "coarse network's backward" % world,
                  desc=("BASELINE configs[4]: training iteration, 4096 rays over %d GPU(s), 64 + 128 samples, stratified "
                        "jitter, forward + backward of both networks + gradient all-reduce + Adam, %s"
-                       % (world, "float32" if args.train_precision == "fp32" else
-                          "bf16 operands, float32 accumulation and parameters")))
+                       % (world, {"fp32": "float32", "bf16x3": "float32 (forward pass in three bf16 terms on the bf16 matrix cores)",
+                                  "bf16": "bf16 operands, float32 accumulation and parameters"}[args.train_precision])))
         it = [0]
 
         def step():

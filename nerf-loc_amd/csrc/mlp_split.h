@@ -1,6 +1,7 @@
 // Host interface of the split-precision network kernels (mlp_split.hip): NERF_PREC_BF16X3 / NERF_PREC_BF16X2.
 #pragma once
 #include "mlp_device.h"
+#include "tape.h"
 
 namespace nerf {
 
@@ -10,5 +11,8 @@ size_t split_packed_bytes(int terms, bool use_viewdirs);          // stream + bi
 int split_samples_per_tile();                                     // samples a workgroup takes per pass
 int launch_pack_split(const PackArgs& a, int terms, bool use_viewdirs, hipStream_t stream);
 int launch_mlp_split(const MlpArgs& a, int terms, bool use_viewdirs, int output_ch, unsigned grid, hipStream_t stream);
+// the training forward in three terms: as launch_mlp_split, and the float32 tape of tape.h is written (M <= 2^22 samples)
+int launch_mlp_split_train(const MlpArgs& a, const TapePtrs& tp, bool use_viewdirs, int output_ch, unsigned grid,
+                           hipStream_t stream);
 
 }  // namespace nerf

@@ -21,47 +21,19 @@
 #include <math.h>
 #include <mutex>
 #include "mlp_device.h"
+#include "mlp_split.h"
+#include "tape.h"
 #include "train_bf16.h"
 #include "wgrad.h"
 
 namespace nerf {
 
-constexpr int TAPE_PE = 64, TAPE_VW = 32;
-// ReLU bits: per sample and ReLU layer (pts_linears.0-7, then views_linears.0) two lane halves x 4 dwords; dword j
-// holds output tiles 2 j (bits 0-15) and 2 j + 1 (bits 16-31), bit e <-> accumulator register e of the tile.  The
-// input-gradient chain reads these instead of the activations.
-constexpr int TAPE_BITS_LAYER = 8;
-constexpr int tape_bits(bool vd) { return (vd ? 9 : 8) * TAPE_BITS_LAYER; }
-constexpr int tape_floats(bool vd) {   // per sample
-    return (vd ? TAPE_PE + TAPE_VW + 8 * 256 + 256 + 128 : TAPE_PE + 8 * 256) + tape_bits(vd);
-}
 constexpr int gtape_floats(bool vd) { return vd ? 8 * 256 + 256 + 128 : 8 * 256; }
 
-struct TapePtrs {
-    float* pe; float* vw; float* h[8]; float* feat; float* hv; unsigned* bits;
-};
 struct GTapePtrs {
     float* dz[8]; float* dfeat; float* dzv;
 };
 
-// Rows are allocated for whole 128-sample workgroup tiles so that the kernels store without bounds checks; rows
-// beyond M hold values of clamped (repeated) inputs and are never read by the weight-gradient kernels.
-static long long pad128(long long M) { return (M + 127) / 128 * 128; }
-
-static TapePtrs tape_ptrs(float* base, long long M, bool vd) {
-    M = pad128(M);
-    TapePtrs t{};
-    size_t o = 0;
-    t.pe = base + o; o += (size_t)M * TAPE_PE;
-    if (vd) { t.vw = base + o; o += (size_t)M * TAPE_VW; }
-    for (int i = 0; i < 8; ++i) { t.h[i] = base + o; o += (size_t)M * 256; }
-    if (vd) {
-        t.feat = base + o; o += (size_t)M * 256;
-        t.hv = base + o; o += (size_t)M * 128;
-    }
-    t.bits = reinterpret_cast<unsigned*>(base + o);
-    return t;
-}
 static GTapePtrs gtape_ptrs(float* base, long long M, bool vd) {
     M = pad128(M);
     GTapePtrs t{};
@@ -388,7 +360,9 @@ static int check_arch(const char* who, int use_viewdirs, int output_ch) {
 }
 static int bwd_frags(int use_viewdirs) { return use_viewdirs ? FRAGS_BWD_F32_VD : FRAGS_BWD_F32_NOVD; }
 
-static bool known_precision(int p) { return p == NERF_PREC_F32 || p == NERF_PREC_BF16; }
+// NERF_PREC_BF16X3 trains with the float32 kernels except for the forward pass, which evaluates the float32 network in
+// three bf16 terms (mlp_split.hip) and writes the same float32 tape
+static bool known_precision(int p) { return p == NERF_PREC_F32 || p == NERF_PREC_BF16 || p == NERF_PREC_BF16X3; }
 
 extern "C" size_t nerf_train_tape_bytes(long long M, int use_viewdirs, int precision) {
     if (M < 0 || !known_precision(precision)) return 0;
@@ -475,6 +449,14 @@ extern "C" int nerf_mlp_forward_train(const void* packed, int precision, int use
     const long long n_tiles = (M + 127) / 128;
     const dim3 grid((unsigned)(n_tiles < cu_count() ? n_tiles : cu_count())), block(MLP_THREADS);
     const TapePtrs tp = tape_ptrs(tape, M, use_viewdirs != 0);
+    if (precision == NERF_PREC_BF16X3) {
+        static_assert(sizeof(float) * 256 == 1024, "the split kernel addresses tape rows with 32-bit byte offsets");
+        NERF_REQUIRE(M <= (1ll << 22), "nerf_mlp_forward_train: at most 4 194 304 samples per launch in bf16x3, got %lld", M);
+        NERF_REQUIRE(split_samples_per_tile() == 128, "nerf_mlp_forward_train: internal tile size mismatch");
+        a.n_stages = split_padded_frags(3, use_viewdirs != 0) / STAGE_FRAGS;
+        a.n_bias_tiles = ((use_viewdirs ? BIAS_TILES16_VD : BIAS_TILES16_NOVD) * 16 + 31) / 32;    // in units of 32 floats
+        return launch_mlp_split_train(a, tp, use_viewdirs != 0, output_ch, grid.x, st);
+    }
     if (use_viewdirs) hipLaunchKernelGGL((mlp_f32_train_kernel<true, 4>), grid, block, 0, st, a, tp);
     else if (output_ch == 4) hipLaunchKernelGGL((mlp_f32_train_kernel<false, 4>), grid, block, 0, st, a, tp);
     else hipLaunchKernelGGL((mlp_f32_train_kernel<false, 5>), grid, block, 0, st, a, tp);

@@ -10,10 +10,13 @@ torch.autograd.Function nodes wrap hand-written HIP kernels:
                 sample positions and view directions have no leaves behind them)
   _CompositeFn  raw2outputs: closed-form backward of the alpha compositing
 
-Training computes in float32 (like the reference) unless bf16 is asked for
-explicitly (set_train_precision("bf16") or a model's ``train_precision``
-attribute): bf16 MFMA operands with float32 accumulation, parameters and
-gradients stay float32.  The inference ``precision`` attribute plays no part.
+Training computes in float32 (like the reference) unless another mode is asked
+for explicitly (set_train_precision(...) or a model's ``train_precision``
+attribute): "bf16x3" evaluates the forward pass of the float32 network in three
+bf16 terms on the bf16 matrix cores (float32 accuracy, same tape, the float32
+backward kernels); "bf16" uses bf16 MFMA operands with float32 accumulation
+throughout, parameters and gradients stay float32.  The inference ``precision``
+attribute plays no part.
 The architecture is the one the
 inference kernels implement (D=8, W=256, skips=[4], with view directions or
 without and output_ch 4 / 5); others raise NotImplementedError.  Nothing here
@@ -32,19 +35,21 @@ _PARAM_ORDER = {True: _TRUNK + ["views_linears.0.weight", "views_linears.0.bias"
                 False: _TRUNK + [None, None, "output_linear.weight", "output_linear.bias"]}
 
 
+TRAIN_PRECISIONS = ("fp32", "bf16x3", "bf16")
 _TRAIN_PRECISION = ["fp32"]
 
 
 def set_train_precision(name):
-    """'fp32' (default: what the reference computes) or 'bf16' for networks without their own ``train_precision``."""
-    if name not in ("fp32", "bf16"):
+    """'fp32' (default: what the reference computes), 'bf16x3' or 'bf16' for networks without their own
+    ``train_precision``."""
+    if name not in TRAIN_PRECISIONS:
         raise ValueError("unknown training precision %r" % (name,))
     _TRAIN_PRECISION[0] = name
 
 
 def train_precision_of(model):
     name = getattr(model, "train_precision", None) or _TRAIN_PRECISION[0]
-    if name not in ("fp32", "bf16"):
+    if name not in TRAIN_PRECISIONS:
         raise ValueError("unknown training precision %r" % (name,))
     return name
 

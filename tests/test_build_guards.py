@@ -36,3 +36,13 @@ def test_stream_checker_sees_a_register_used_before_its_wait():
     assert any("line 2" in f for f in kernel_guard.check_stream(copy_before_wait))
     lds_dma = [(1, "global_load_lds_dwordx4 v[0:1], off"), (2, "v_mov_b32_e32 v0, v1"), (3, "s_waitcnt vmcnt(0)")]
     assert kernel_guard.check_stream(lds_dma) == []
+
+
+def test_scratch_is_tolerated_only_outside_the_layer_loop():
+    mfma = "v_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]"
+    before = [(0, "scratch_store_dword off, v2, off offset:16"), (1, mfma), (2, "v_add_u32_e32 v0, v1, v2"), (3, mfma),
+              (4, "scratch_load_dword v2, off, off offset:16")]
+    assert kernel_guard.scratch_in_layer_loop(before) == []
+    inside = [(0, mfma), (1, "scratch_load_dword v2, off, off offset:16"), (2, mfma)]
+    found = kernel_guard.scratch_in_layer_loop(inside)
+    assert len(found) == 1 and "line 1" in found[0]

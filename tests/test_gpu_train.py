@@ -400,3 +400,125 @@ def test_gradient_exchange_direct_write_equals_autograd_path(dev, precision):
     ex.finish()
     opt.step()
     assert torch.isfinite(nc.alpha_linear.weight).all()
+
+
+def _tape_sections(tape, M, vd):
+    """The float32 tape as named [rows, width] views (layout of nerf-loc_amd/csrc/tape.h: rows padded to 128 samples)."""
+    Mp = (M + 127) // 128 * 128
+    widths = [("pe", 64)] + ([("vw", 32)] if vd else []) + [("h%d" % i, 256) for i in range(8)] + \
+        ([("feat", 256), ("hv", 128)] if vd else [])
+    out, o = {}, 0
+    for k, w in widths:
+        out[k] = tape[o:o + Mp * w].reshape(Mp, w)[:M]
+        o += Mp * w
+    nb = (9 if vd else 8) * 8
+    out["bits"] = tape[o:o + Mp * nb].view(torch.int32).reshape(Mp, nb)[:M]
+    return out
+
+
+@pytest.mark.parametrize("vd,out_ch,mode", [(True, 4, "rays"), (True, 4, "features"), (False, 4, "rays"), (False, 5, "features"),
+                                            (True, 4, "points")])
+def test_split_training_forward_writes_the_float32_tape(dev, vd, out_ch, mode):
+    """nerf_mlp_forward_train in bf16x3 (the float32 network in three bf16 terms) against the float32 kernel: outputs
+    to float32 accuracy and the SAME tape - encodings, every layer's activations, the ReLU bits - so that the float32
+    backward kernels run on it unchanged.  Bits may differ only where the activation itself is within rounding of
+    zero.  Then the gradients of both tapes through nerf_mlp_backward."""
+    from nerf_loc_amd import hip, train
+    R, S = 37, 64                     # 2368 samples: 18.5 workgroup tiles, the last one ragged
+    M = R * S
+    sd = synth.make_state_dict(31, "B") if vd else synth.make_state_dict(31, "B", use_viewdirs=False, output_ch=out_ch,
+                                                                         input_ch_views=0)
+    net = load_net(sd, dev, use_viewdirs=vd, output_ch=out_ch)
+    rays = T(synth.random_rays(R, seed=9), dev)
+    if not vd:
+        rays = rays[:, :8].contiguous()
+    z = hip.z_vals(rays, S)
+    if mode == "rays":
+        args = (hip.IN_RAYS, rays, z, R, S, rays.shape[1])
+    else:
+        pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]).reshape(-1, 3).contiguous()
+        if mode == "points":
+            args = (hip.IN_POINTS, pts, rays[:, 8:11].contiguous(), R, S, 0)
+        else:
+            x = N(pts)
+            feat = orc.embed(x, 10)
+            if vd:
+                d = np.repeat(N(rays[:, 8:11]), S, axis=0)
+                feat = np.concatenate([feat, orc.embed(d, 4)], -1)
+            args = (hip.IN_FEATURES, T(feat.astype(F32), dev), None, M, 1, 0)
+    res = {}
+    for prec in ("fp32", "bf16x3"):
+        packed = net.packed_weights(hip.PRECISIONS[prec])
+        raw, tape = hip.mlp_forward_train(packed, vd, out_ch, *args, precision=prec)
+        res[prec] = (raw, tape, packed)
+    raw32, raw3 = res["fp32"][0], res["bf16x3"][0]
+    assert relerr(N(raw3), N(raw32)) < 2e-5
+    t32, t3 = _tape_sections(res["fp32"][1], M, vd), _tape_sections(res["bf16x3"][1], M, vd)
+    for k in t32:
+        if k == "bits":
+            continue
+        a, b = N(t3[k]).astype(np.float64), N(t32[k]).astype(np.float64)
+        # sin / cos of the encodings: the float32 library functions in one kernel, its own polynomial in the other
+        bar = 2e-6 if k in ("pe", "vw") else 2e-5
+        assert np.abs(a - b).max() <= bar * max(1.0, np.abs(b).max()), (k, np.abs(a - b).max(), np.abs(b).max())
+    # ReLU bits: bit e of tile t (16-bit half of a dword) <-> feature 32 t + (e & 3) + 8 (e >> 2) + 4 h
+    b32, b3 = N(t32["bits"]).view(np.uint32), N(t3["bits"]).view(np.uint32)
+    assert b32.shape == b3.shape
+    n_layers = 9 if vd else 8
+    flipped, flipped_rows = 0, np.zeros(M, bool)
+    for layer in range(n_layers):
+        act = N(t32["hv" if layer == 8 else "h%d" % layer])
+        width = act.shape[1]
+        want = np.zeros((M, width), bool)
+        for h in range(2):
+            for j in range(4):
+                for half in range(2):
+                    t = 2 * j + half
+                    if 32 * t >= width:
+                        continue
+                    word = (b3[:, layer * 8 + h * 4 + j] >> (16 * half)) & 0xffff
+                    for e in range(16):
+                        want[:, 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h] = (word >> e) & 1
+        if layer == 8:       # dwords 2, 3 of both halves are unused by a 128-wide layer: zero, as the float32 kernel leaves them
+            assert not b3[:, 64 + 2:64 + 4].any() and not b3[:, 64 + 6:64 + 8].any()
+        got3 = N(t3["hv" if layer == 8 else "h%d" % layer]) > 0
+        assert np.array_equal(want, got3), layer                        # the bits describe the kernel's own activations
+        diff = want != (act > 0)
+        flipped += int(diff.sum())
+        flipped_rows |= diff.any(axis=1)
+        assert (np.abs(act[diff]) < 1e-5).all(), layer                  # and differ from float32's only at the threshold
+    print("%s vd=%d: raw %.1e, ReLU decisions that differ from the float32 kernel's: %d of %d"
+          % (mode, vd, relerr(N(raw3), N(raw32)), flipped, M * (8 * 256 + (128 if vd else 0))))
+    # the same backward kernels on both tapes.  A sample with a ReLU decided the other way sends its whole upstream
+    # gradient down a different path (one such sample moves pts_linears.0.weight.grad by 7e-3 of its largest entry):
+    # those samples get a zero upstream gradient, the rest must agree to rounding
+    params = train._params(net)
+    shapes = [None if p is None else tuple(p.shape) for p in params]
+    packed_bwd = hip.mlp_pack_backward([None if p is None else p.detach() for p in params], vd, out_ch, "fp32")
+    d_raw = torch.randn(M, out_ch, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    d_raw[T(flipped_rows, dev)] = 0.0
+    g32 = hip.mlp_backward(packed_bwd, vd, out_ch, d_raw, res["fp32"][1], shapes, precision="fp32")
+    g3 = hip.mlp_backward(packed_bwd, vd, out_ch, d_raw, res["bf16x3"][1], shapes, precision="bf16x3")
+    for i, (a, b) in enumerate(zip(g3, g32)):
+        if b is not None:
+            assert relerr(N(a), N(b)) < 1e-4, (i, relerr(N(a), N(b)))
+
+
+def test_train_step_in_three_terms_matches_reference_autograd(dev, golden):
+    """The reference's training step (tests/golden/g8_train_step.npz) with train_precision 'bf16x3': the same bars as
+    the float32 kernels."""
+    from nerf_loc_amd import render, helpers
+    g = golden("g8_train_step")
+    rays, target = T(g["rays"], dev), T(g["target"], dev)
+    nc, nf = load_net(synth.make_state_dict(80, "B"), dev), load_net(synth.make_state_dict(81, "B"), dev)
+    nc.train_precision = nf.train_precision = "bf16x3"
+    r = render.render_rays(rays, nc, _query(dev), 64, N_importance=128, network_fine=nf, white_bkgd=True, retraw=True,
+                           perturb=0.0, raw_noise_std=0.0)
+    l1, l0 = helpers.img2mse(r["rgb_map"], target), helpers.img2mse(r["rgb0"], target)
+    loss = l1 + l0
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["det_loss"])) < 2e-6
+    wc = _grads_close(g, "det", "c", nc, 1e-4)
+    wf = _grads_close(g, "det", "f", nf, 5e-3)
+    print("bf16x3 training step: loss %.8f (reference %.8f), worst gradient error coarse %.2e, fine %.2e"
+          % (float(loss.detach()), float(g["det_loss"]), wc, wf))

@@ -7,7 +7,9 @@ is issued, so nothing but the code's structure keeps it from copying, re-using o
 has landed.  This tool reads the gfx950 code objects out of the built libnerf_hip.so and checks, per kernel,
 
   1. resources: no scratch memory (a spill of a load's destination to memory between the load and its wait would store
-     a stale value); where every load is hand-counted (2.) no register spill of any kind;
+     a stale value); where every load is hand-counted (2.) no register spill of any kind.  One kernel is allowed a
+     few spill slots (PROLOGUE_SCRATCH: it loads nothing into registers by hand), but only outside its layer loop: no
+     scratch instruction may sit between its first and its last MFMA;
   2. the instruction stream: every vector-memory load into registers is tracked in issue order; `s_waitcnt vmcnt(N)`
      retires all but the N youngest vector-memory operations (loads, stores and LDS-DMA count together, in order); an
      instruction that reads or overwrites a register an outstanding load still has to write is reported.  The listing
@@ -27,12 +29,14 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 # kernels with hand-counted waits (substrings of the demangled-ish symbol)
-GUARDED = ("wgrad_kernel", "wgrad16_kernel", "mlp16_bf16_kernel", "mlp_split_kernel", "mlp_bf16_kernel",
+GUARDED = ("wgrad_kernel", "wgrad16_kernel", "mlp16_bf16_kernel", "mlp_split_kernel", "mlp_split_train_kernel", "mlp_bf16_kernel",
            "mlp_dgrad_bf16_kernel")
 # of these, the kernels whose EVERY load into registers is hand-counted inline asm: only there is the linear walk of the
 # instruction stream meaningful (compiler-managed loads sit in branches a linear walk cannot follow, and the compiler
 # places their waits itself); the LDS-DMA of the other kernels has no destination register to watch
 STREAM_CHECKED = ("wgrad_kernel",)
+# kernel -> bytes of scratch per lane it may use in front of its first MFMA (loop invariants of the encoding phase)
+PROLOGUE_SCRATCH = {"mlp_split_train_kernel": 64}
 
 
 def code_objects(lib_path):
@@ -118,6 +122,15 @@ def check_stream(lines):
     return sorted(set(findings))
 
 
+def scratch_in_layer_loop(lines):
+    """Findings for scratch instructions between the first and the last MFMA of a kernel's listing."""
+    mfma = [i for i, (_, text) in enumerate(lines) if text.startswith("v_mfma")]
+    if not mfma:
+        return []
+    return ["line %d `%s`: scratch access inside the layer loop" % (no, text.strip())
+            for i, (no, text) in enumerate(lines) if mfma[0] < i < mfma[-1] and text.startswith("scratch_")]
+
+
 def kernel_streams(elf_path):
     txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", elf_path], capture_output=True,
                          text=True, check=True).stdout
@@ -148,8 +161,13 @@ def run(lib_path, only=()):
                     continue
                 probs = []
                 strict = any(g in name for g in STREAM_CHECKED)      # elsewhere spills stay in registers (scratch 0 B)
-                if k.get("private_segment_fixed_size", 0) or (strict and (k.get("vgpr_spill_count", 0) or
-                                                                          k.get("sgpr_spill_count", 0))):
+                allowed = max([v for g, v in PROLOGUE_SCRATCH.items() if g in name] + [0])
+                scratch = k.get("private_segment_fixed_size", 0)
+                if scratch and scratch <= allowed:
+                    if streams is None:
+                        streams = kernel_streams(path)
+                    probs += scratch_in_layer_loop(streams.get(name, []))
+                elif scratch or (strict and (k.get("vgpr_spill_count", 0) or k.get("sgpr_spill_count", 0))):
                     probs.append("scratch %d B, %d VGPR spills, %d SGPR spills" % (k.get("private_segment_fixed_size", 0),
                                                                                    k.get("vgpr_spill_count", 0),
                                                                                    k.get("sgpr_spill_count", 0)))

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"])
     ap.add_argument("--no-exchange", action="store_true", help="ordinary autograd gradients instead of the flat buffer")
     args = ap.parse_args()
     from nerf_loc_amd import dist as ndist, helpers, render, synth, train
