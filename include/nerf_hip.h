@@ -36,7 +36,7 @@ extern "C" {
                               /* inference, v_mfma_f32_32x32x16_bf16 in the training kernels)        */
 #define NERF_PREC_BF16X3 2    /* float32 accuracy on the bf16 matrix cores: every operand a sum of   */
                               /* three bf16 terms, the six leading products per element, float32    */
-                              /* accumulation (inference entry points only)                         */
+                              /* accumulation (inference; training: the forward pass, see below)    */
 #define NERF_PREC_BF16X2 3    /* two bf16 terms, three products: operands good to 2^-16              */
 
 /* what nerf_mlp_forward reads as its input */
@@ -47,8 +47,9 @@ extern "C" {
 
 /* Version of this interface (2: the training entry points take a `precision` argument; 3: adds
  * nerf_mlp_backward_static; 4: adds nerf_mlp_forward_objects; 5: adds nerf_make_rays_views; 6: the inference entry
- * points accept NERF_PREC_BF16X3 / NERF_PREC_BF16X2; adds nerf_render_rays; nerf_raw2outputs_backward takes g_weights). */
-#define NERF_HIP_ABI_VERSION 6
+ * points accept NERF_PREC_BF16X3 / NERF_PREC_BF16X2; adds nerf_render_rays; nerf_raw2outputs_backward takes g_weights;
+ * 7: the training entry points accept NERF_PREC_BF16X3). */
+#define NERF_HIP_ABI_VERSION 7
 int nerf_hip_abi_version(void);
 const char* nerf_last_error(void);
 
@@ -209,9 +210,12 @@ int nerf_render_rays(const void* packed_coarse, const void* packed_fine_or_null,
  * loss.backward() -> Adam).  These entry points produce what autograd would: gradients of a
  * scalar loss with respect to raw (compositing) and to the 24 parameter tensors (network), for
  * the D=8 / W=256 architecture (with or without view directions).  `precision` selects the
- * arithmetic of the network kernels: NERF_PREC_F32 (exact float32 MFMA) or NERF_PREC_BF16 (bf16
- * operands, float32 accumulation; parameters and gradients stay float32).  Tapes, packed
- * streams and entry points of one training step must all use the same precision.
+ * arithmetic of the network kernels: NERF_PREC_F32 (exact float32 MFMA), NERF_PREC_BF16 (bf16
+ * operands, float32 accumulation; parameters and gradients stay float32) or NERF_PREC_BF16X3:
+ * the forward pass evaluates the float32 network in three bf16 terms (float32 accuracy at 0.66 of
+ * the exact kernel's time) and writes the float32 tape; sizes, backward stream and backward kernels
+ * are the float32 ones; at most 4 194 304 samples per forward launch.  Tapes, packed streams and
+ * entry points of one training step must all use the same precision.
  *
  * nerf_raw2outputs_backward: backward of raw2outputs (run_nerf.py:268-311).  g_rgb [R,3], g_disp,
  * g_acc, g_depth [R] and g_weights [R,S] are the upstream gradients of the maps and of the

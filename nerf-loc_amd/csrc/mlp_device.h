@@ -130,7 +130,11 @@ struct Pipe {
     // Issue one more stage, then make the oldest outstanding one visible to the workgroup.
     __device__ __forceinline__ void advance() {
         issue();
+#ifdef NERF_EXP_LAXWAIT      // timing experiment only (results are garbage): twelve more operations may stay in flight
+        asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(" NERF_VMCNT_KEEP ")" ::: "memory");
+#endif
 #ifndef NERF_EXP_NOBARRIER
         __builtin_amdgcn_s_barrier();
 #endif

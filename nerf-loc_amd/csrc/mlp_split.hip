@@ -153,7 +153,11 @@ __device__ __forceinline__ void convert_slice(const f32x4v (*src)[NCT], bool rel
         v.x = relu ? relu1(acc[0]) : acc[0]; v.y = relu ? relu1(acc[1]) : acc[1];
         v.z = relu ? relu1(acc[2]) : acc[2]; v.w = relu ? relu1(acc[3]) : acc[3];
         const unsigned off = (td.ld == 256 ? tc.rowb[ct] : tc.rowb[ct] >> 1) + tc.g16;
+#ifndef NERF_SPX_NOTAPESTORE      // timing experiment only (the tape is garbage): what the activation stores cost
         *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(td.base) + off + 64 * tile) = v;
+#else
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(off));
+#endif
         if (relu) {
             const unsigned n = positive_bit(v.x) | (positive_bit(v.y) << 1) | (positive_bit(v.z) << 2) | (positive_bit(v.w) << 3);
             tc.nib[ct][tile >> 3] |= n << (4 * (tile & 7));
@@ -634,6 +638,12 @@ int split_samples_per_tile() { return sp::TILE; }
 
 int launch_mlp_split_train(const MlpArgs& a, const TapePtrs& tp, bool use_viewdirs, int output_ch, unsigned grid, hipStream_t st) {
     const dim3 g(grid), b(MLP_THREADS);
+#ifdef NERF_EXP_ONLY_VD           // experiment builds only: a third of the compile time
+    NERF_REQUIRE(use_viewdirs, "experiment build: view directions only");
+    hipLaunchKernelGGL((sp::mlp_split_train_kernel<3, true, 4>), g, b, 0, st, a, tp);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+#endif
     if (use_viewdirs) hipLaunchKernelGGL((sp::mlp_split_train_kernel<3, true, 4>), g, b, 0, st, a, tp);
     else if (output_ch == 4) hipLaunchKernelGGL((sp::mlp_split_train_kernel<3, false, 4>), g, b, 0, st, a, tp);
     else hipLaunchKernelGGL((sp::mlp_split_train_kernel<3, false, 5>), g, b, 0, st, a, tp);
@@ -643,6 +653,12 @@ int launch_mlp_split_train(const MlpArgs& a, const TapePtrs& tp, bool use_viewdi
 
 int launch_mlp_split(const MlpArgs& a, int terms, bool use_viewdirs, int output_ch, unsigned grid, hipStream_t st) {
     const dim3 g(grid), b(MLP_THREADS);
+#ifdef NERF_EXP_ONLY_VD
+    NERF_REQUIRE(use_viewdirs && terms == 3, "experiment build: view directions and three terms only");
+    hipLaunchKernelGGL((sp::mlp_split_kernel<3, true, 4>), g, b, 0, st, a);
+    NERF_LAUNCH_CHECK();
+    return NERF_OK;
+#endif
     if (terms == 3) {
         if (use_viewdirs) hipLaunchKernelGGL((sp::mlp_split_kernel<3, true, 4>), g, b, 0, st, a);
         else if (output_ch == 4) hipLaunchKernelGGL((sp::mlp_split_kernel<3, false, 4>), g, b, 0, st, a);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "lib", "libnerf_hip.so")
 
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X2 = 0, 1, 2, 3
-ABI_VERSION = 6      # 2: training entry points take a precision; 3: nerf_mlp_backward_static; 4: nerf_mlp_forward_objects;
+ABI_VERSION = 7      # 2: training entry points take a precision; 3: nerf_mlp_backward_static; 4: nerf_mlp_forward_objects;
                      # 5: nerf_make_rays_views; 6: the bf16x3 / bf16x2 precision codes
 IN_FEATURES, IN_POINTS, IN_RAYS = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16,

@@ -17,6 +17,7 @@ ap.add_argument("--rays", type=int, default=163840)
 ap.add_argument("--samples", type=int, default=192)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--novd", action="store_true")
+ap.add_argument("--train", action="store_true", help="the training forward (keeps its tape) instead of the inference kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 vd = not a.novd
@@ -30,21 +31,37 @@ rays = torch.from_numpy(synth.random_rays(a.rays, seed=0)).to(dev)
 if not vd:
     rays = rays[:, :8].contiguous()
 z = hip.z_vals(rays, a.samples)
-out = hip.mlp_forward(packed, prec, vd, 4, hip.IN_RAYS, rays, z, a.rays, a.samples, rays.shape[1])
+if a.train:
+    M_ = a.rays * a.samples
+    tape_buf = torch.empty((hip.lib().nerf_train_tape_bytes(M_, int(vd), prec) // 4,), dtype=torch.float32, device=dev)
+    out_buf = torch.empty((M_, 4), dtype=torch.float32, device=dev)
+    import ctypes
+
+    def forward():      # the entry point itself: the binding would allocate a tape per call
+        with torch.cuda.device(dev):
+            hip._check(hip.lib().nerf_mlp_forward_train(ctypes.c_void_p(packed.data_ptr()), prec, int(vd), 4, hip.IN_RAYS,
+                                                        hip._ptr(rays), hip._ptr(z), a.rays, a.samples, rays.shape[1],
+                                                        hip._ptr(out_buf), ctypes.c_void_p(tape_buf.data_ptr()),
+                                                        hip._stream(out_buf)), "nerf_mlp_forward_train")
+        return out_buf
+else:
+    def forward():
+        return hip.mlp_forward(packed, prec, vd, 4, hip.IN_RAYS, rays, z, a.rays, a.samples, rays.shape[1])
+out = forward()
 torch.cuda.synchronize()
 ts = []
 for _ in range(a.reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    out = hip.mlp_forward(packed, prec, vd, 4, hip.IN_RAYS, rays, z, a.rays, a.samples, rays.shape[1])
+    out = forward()
     e1.record()
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 M = a.rays * a.samples
 t = float(np.median(ts))
 fl = 1186816 if vd else 2 * 492032
-print("mlp %s vd=%d: %d samples, median %.3f ms (min %.3f), %.1f TFLOP/s, %.2f ns per sample and CU, checksum %.6f"
-      % (a.precision, vd, M, t, min(ts), M * fl / t / 1e9, t * 1e6 / (M / 256), float(out.abs().mean())))
+print("mlp %s%s vd=%d: %d samples, median %.3f ms (min %.3f), %.1f TFLOP/s, %.2f ns per sample and CU, checksum %.6f"
+      % (a.precision, " train" if a.train else "", vd, M, t, min(ts), M * fl / t / 1e9, t * 1e6 / (M / 256), float(out.abs().mean())))
 try:   # diagnostic builds only (NERF_EXP_STAMP): per-block cycle sums of the sections of a pass
     import ctypes
     fn = hip.lib().nerf_debug_read_stamps
