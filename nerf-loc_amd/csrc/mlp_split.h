@@ -15,4 +15,11 @@ int launch_mlp_split(const MlpArgs& a, int terms, bool use_viewdirs, int output_
 int launch_mlp_split_train(const MlpArgs& a, const TapePtrs& tp, bool use_viewdirs, int output_ch, unsigned grid,
                            hipStream_t stream);
 
+// the input-gradient chain in three terms (dgrad_split.hip): transposed stream, packer, launch.  `bits`: the ReLU bits of
+// the forward tape; the gradient tape is written in the float32 layout (M <= 2^22 samples)
+int split_bwd_padded_frags(bool use_viewdirs);
+int launch_pack_split_backward(const float* const* tensors, bool use_viewdirs, int output_ch, void* packed_out, hipStream_t stream);
+int launch_split_dgrad(const void* packed_bwd, bool use_viewdirs, int output_ch, const float* d_raw, long long M,
+                       const unsigned* bits, const GTapePtrs& gt, unsigned grid, hipStream_t stream);
+
 }  // namespace nerf

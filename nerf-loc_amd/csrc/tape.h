@@ -43,4 +43,23 @@ inline TapePtrs tape_ptrs(float* base, long long M, bool vd) {
     return t;
 }
 
+// The gradient tape (scratch of the backward): the gradient at every pre-activation, same row layout.
+constexpr int gtape_floats(bool vd) { return vd ? 8 * 256 + 256 + 128 : 8 * 256; }
+
+struct GTapePtrs {
+    float* dz[8]; float* dfeat; float* dzv;
+};
+
+inline GTapePtrs gtape_ptrs(float* base, long long M, bool vd) {
+    M = pad128(M);
+    GTapePtrs t{};
+    size_t o = 0;
+    for (int i = 0; i < 8; ++i) { t.dz[i] = base + o; o += (size_t)M * 256; }
+    if (vd) {
+        t.dfeat = base + o; o += (size_t)M * 256;
+        t.dzv = base + o;
+    }
+    return t;
+}
+
 }  // namespace nerf

@@ -28,24 +28,6 @@
 
 namespace nerf {
 
-constexpr int gtape_floats(bool vd) { return vd ? 8 * 256 + 256 + 128 : 8 * 256; }
-
-struct GTapePtrs {
-    float* dz[8]; float* dfeat; float* dzv;
-};
-
-static GTapePtrs gtape_ptrs(float* base, long long M, bool vd) {
-    M = pad128(M);
-    GTapePtrs t{};
-    size_t o = 0;
-    for (int i = 0; i < 8; ++i) { t.dz[i] = base + o; o += (size_t)M * 256; }
-    if (vd) {
-        t.dfeat = base + o; o += (size_t)M * 256;
-        t.dzv = base + o;
-    }
-    return t;
-}
-
 // per-tile hooks -----------------------------------------------------------------------------
 // Accumulator register 4 g + k of tile t holds feature 32 t + 8 g + 4 h + k of the lane's sample: four
 // 16-byte pieces per tile and lane in a sample-major row.
@@ -360,8 +342,8 @@ static int check_arch(const char* who, int use_viewdirs, int output_ch) {
 }
 static int bwd_frags(int use_viewdirs) { return use_viewdirs ? FRAGS_BWD_F32_VD : FRAGS_BWD_F32_NOVD; }
 
-// NERF_PREC_BF16X3 trains with the float32 kernels except for the forward pass, which evaluates the float32 network in
-// three bf16 terms (mlp_split.hip) and writes the same float32 tape
+// NERF_PREC_BF16X3 trains on the float32 tapes: forward pass (mlp_split.hip) and input-gradient chain (dgrad_split.hip)
+// evaluate the float32 network in three bf16 terms, the weight gradients are the float32 kernels'.
 static bool known_precision(int p) { return p == NERF_PREC_F32 || p == NERF_PREC_BF16 || p == NERF_PREC_BF16X3; }
 
 extern "C" size_t nerf_train_tape_bytes(long long M, int use_viewdirs, int precision) {
@@ -381,6 +363,7 @@ extern "C" size_t nerf_mlp_backward_packed_bytes(int use_viewdirs, int precision
     if (!known_precision(precision)) return 0;
     if (precision == NERF_PREC_BF16)
         return (size_t)pad_to_stage(use_viewdirs ? FRAGS_BWD_BF16_VD : FRAGS_BWD_BF16_NOVD) * FRAG_BYTES;
+    if (precision == NERF_PREC_BF16X3) return (size_t)split_bwd_padded_frags(use_viewdirs != 0) * FRAG_BYTES;
     return (size_t)pad_to_stage(bwd_frags(use_viewdirs)) * FRAG_BYTES;
 }
 
@@ -392,6 +375,12 @@ extern "C" int nerf_mlp_pack_backward(const float* const* tensors_host, int use_
     NERF_REQUIRE(((uintptr_t)packed_out & 15) == 0, "nerf_mlp_pack_backward: packed_out must be 16-byte aligned");
     if (precision == NERF_PREC_BF16)
         return pack_backward_bf16(tensors_host, use_viewdirs != 0, output_ch, packed_out, as_stream(stream));
+    if (precision == NERF_PREC_BF16X3) {
+        const int n_tensors = use_viewdirs ? 24 : 20;
+        for (int i = 0; i < n_tensors; i += 2)
+            if (use_viewdirs || i != 16) NERF_REQUIRE(tensors_host[i], "nerf_mlp_pack_backward: weight tensor %d is null", i);
+        return launch_pack_split_backward(tensors_host, use_viewdirs != 0, output_ch, packed_out, as_stream(stream));
+    }
     PackArgs a;
     a.net = make_backward_desc(use_viewdirs != 0, output_ch);
     a.bf16 = 0;
@@ -487,16 +476,21 @@ extern "C" int nerf_mlp_backward(const void* packed_bwd, const void* packed_fwd,
                              grads_host, st);
     const TapePtrs tp = tape_ptrs(const_cast<float*>(tape), M, use_viewdirs != 0);
     const GTapePtrs gt = gtape_ptrs(grad_tape, M, use_viewdirs != 0);
+    const long long n_tiles = (M + 127) / 128;
+    const dim3 grid((unsigned)(n_tiles < cu_count() ? n_tiles : cu_count())), block(MLP_THREADS);
+    if (precision == NERF_PREC_BF16X3) {
+        NERF_REQUIRE(M <= (1ll << 22), "nerf_mlp_backward: at most 4 194 304 samples per call in bf16x3, got %lld", M);
+        if (int rc = launch_split_dgrad(packed_bwd, use_viewdirs != 0, output_ch, d_raw, M, tp.bits, gt, grid.x, st)) return rc;
+    } else {
     DgradArgs d;
     d.packed = static_cast<const unsigned char*>(packed_bwd);
     d.n_stages = pad_to_stage(bwd_frags(use_viewdirs)) / STAGE_FRAGS;
     d.M = M; d.d_raw = d_raw; d.tp = tp; d.gt = gt;
-    const long long n_tiles = (M + 127) / 128;
-    const dim3 grid((unsigned)(n_tiles < cu_count() ? n_tiles : cu_count())), block(MLP_THREADS);
     if (use_viewdirs) hipLaunchKernelGGL((mlp_dgrad_f32_kernel<true, 4>), grid, block, 0, st, d);
     else if (output_ch == 4) hipLaunchKernelGGL((mlp_dgrad_f32_kernel<false, 4>), grid, block, 0, st, d);
     else hipLaunchKernelGGL((mlp_dgrad_f32_kernel<false, 5>), grid, block, 0, st, d);
     NERF_LAUNCH_CHECK();
+    }
 
     // state_dict order: pts_linears.i -> 2i, 2i+1; views_linears.0 16, 17; then with view directions feature 18, 19,
     // alpha 20, 21, rgb 22, 23; without them output_linear 18, 19 (views_linears.0 is unused and gets no gradient)

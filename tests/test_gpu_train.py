@@ -498,9 +498,14 @@ def test_split_training_forward_writes_the_float32_tape(dev, vd, out_ch, mode):
     d_raw = torch.randn(M, out_ch, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
     d_raw[T(flipped_rows, dev)] = 0.0
     g32 = hip.mlp_backward(packed_bwd, vd, out_ch, d_raw, res["fp32"][1], shapes, precision="fp32")
-    g3 = hip.mlp_backward(packed_bwd, vd, out_ch, d_raw, res["bf16x3"][1], shapes, precision="bf16x3")
-    for i, (a, b) in enumerate(zip(g3, g32)):
+    # the input-gradient chain in three terms (its own transposed stream) on the three-term forward's tape, and, to tell
+    # the two kernels apart, on the float32 forward's tape as well
+    packed_bwd3 = hip.mlp_pack_backward([None if p is None else p.detach() for p in params], vd, out_ch, "bf16x3")
+    g3 = hip.mlp_backward(packed_bwd3, vd, out_ch, d_raw, res["bf16x3"][1], shapes, precision="bf16x3")
+    g3_on32 = hip.mlp_backward(packed_bwd3, vd, out_ch, d_raw, res["fp32"][1], shapes, precision="bf16x3")
+    for i, (a, a32, b) in enumerate(zip(g3, g3_on32, g32)):
         if b is not None:
+            assert relerr(N(a32), N(b)) < 2e-5, (i, "dgrad alone", relerr(N(a32), N(b)))
             assert relerr(N(a), N(b)) < 1e-4, (i, relerr(N(a), N(b)))
 
 

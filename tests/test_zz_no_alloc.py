@@ -30,7 +30,7 @@ def _net(dev, vd):
     return net.to(dev)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("vd", [True, False])
 def test_static_backward_equals_backward(dev, precision, vd):
     from nerf_loc_amd import hip, train

@@ -29,7 +29,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 # kernels with hand-counted waits (substrings of the demangled-ish symbol)
-GUARDED = ("wgrad_kernel", "wgrad16_kernel", "mlp16_bf16_kernel", "mlp_split_kernel", "mlp_split_train_kernel", "mlp_bf16_kernel",
+GUARDED = ("wgrad_kernel", "wgrad16_kernel", "mlp16_bf16_kernel", "mlp_split_kernel", "mlp_split_train_kernel", "mlp_split_dgrad_kernel",
+           "mlp_bf16_kernel",
            "mlp_dgrad_bf16_kernel")
 # of these, the kernels whose EVERY load into registers is hand-counted inline asm: only there is the linear walk of the
 # instruction stream meaningful (compiler-managed loads sit in branches a linear walk cannot follow, and the compiler
