@@ -471,6 +471,18 @@ def main(argv=None):
                 roof = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
                         "kernel": "whole iteration (mlp_bf16_kernel<TAPE> + mlp_dgrad_bf16_kernel + wgrad16_kernel): "
                                   "%d B of tape traffic per sample / step time; %.0f TFLOP/s at 3 x forward FLOPs" % (tape_bytes, ach)}
+            elif precision == "bf16x3":
+                # two pipes: forward and input-gradient chain issue six bf16 products per multiply-add (bound: the bf16
+                # peak), the weight gradients are exact float32 MFMA (bound: the float32 peak).  frac = the time both
+                # would take at their peaks / the measured step.
+                fwd, dgrad = FLOP_PER_SAMPLE, 2 * 16 * 32 * 1112      # per sample; 1112 transposed 16 x 32 fragments per term
+                ideal = n_rays * 192 * (6 * (fwd + dgrad) / (PEAK_TFLOPS["bf16"] * 1e12) + fwd / (PEAK_TFLOPS["fp32"] * 1e12))
+                roof = {"bound": "mfma", "achieved": ach, "peak": None, "unit": "TFLOP/s", "frac": ideal * args.steps / dt,
+                        "traffic": None,
+                        "kernel": "whole iteration (mlp_split_train_kernel + mlp_split_dgrad_kernel: six bf16 products per "
+                                  "multiply-add against %.0f TFLOP/s; wgrad_kernel: float32 MFMA against %.1f TFLOP/s); achieved = "
+                                  "3 x forward FLOPs per sample / step time, frac = time at those peaks / step time"
+                                  % (PEAK_TFLOPS["bf16"], PEAK_TFLOPS["fp32"])}
             else:
                 roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                         "kernel": "whole iteration (mlp_f32_train_kernel + mlp_dgrad_f32_kernel + wgrad_kernel), "

@@ -212,9 +212,10 @@ int nerf_render_rays(const void* packed_coarse, const void* packed_fine_or_null,
  * the D=8 / W=256 architecture (with or without view directions).  `precision` selects the
  * arithmetic of the network kernels: NERF_PREC_F32 (exact float32 MFMA), NERF_PREC_BF16 (bf16
  * operands, float32 accumulation; parameters and gradients stay float32) or NERF_PREC_BF16X3:
- * the forward pass evaluates the float32 network in three bf16 terms (float32 accuracy at 0.66 of
- * the exact kernel's time) and writes the float32 tape; sizes, backward stream and backward kernels
- * are the float32 ones; at most 4 194 304 samples per forward launch.  Tapes, packed streams and
+ * forward pass and input-gradient chain evaluate the float32 network in three bf16 terms (float32
+ * accuracy at about 0.67 of the exact kernels' time) on the float32 tapes, whose sizes are the
+ * float32 ones; the weight gradients are the float32 kernels'; the backward stream is its own
+ * (nerf_mlp_backward_packed_bytes); at most 4 194 304 samples per call.  Tapes, packed streams and
  * entry points of one training step must all use the same precision.
  *
  * nerf_raw2outputs_backward: backward of raw2outputs (run_nerf.py:268-311).  g_rgb [R,3], g_disp,
