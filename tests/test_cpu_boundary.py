@@ -124,6 +124,15 @@ def test_training_entry_points_check_precision_and_sizes():
     assert lib.nerf_train_grad_tape_bytes(256, 0, b16) == 4 * 130 * 2048
     assert lib.nerf_mlp_backward_packed_bytes(1, f32) == 2192 * 1024 and lib.nerf_mlp_backward_packed_bytes(0, f32) == 1808 * 1024
     assert lib.nerf_mlp_backward_packed_bytes(1, b16) == 1104 * 1024 and lib.nerf_mlp_backward_packed_bytes(0, b16) == 912 * 1024
+    # bf16x3 trains on the float32 tapes; its input-gradient chain has a stream of its own (3 terms x 1112 / 912
+    # transposed 16 x 32 fragments, padded to whole stages of 16); bf16x2 is an inference mode only
+    x3 = hip.PREC_BF16X3
+    for M in (1, 129, 5000):
+        for vd in (0, 1):
+            assert lib.nerf_train_tape_bytes(M, vd, x3) == lib.nerf_train_tape_bytes(M, vd, f32)
+            assert lib.nerf_train_grad_tape_bytes(M, vd, x3) == lib.nerf_train_grad_tape_bytes(M, vd, f32)
+    assert lib.nerf_mlp_backward_packed_bytes(1, x3) == 3344 * 1024 and lib.nerf_mlp_backward_packed_bytes(0, x3) == 2736 * 1024
+    assert lib.nerf_train_tape_bytes(100, 1, hip.PREC_BF16X2) == 0 and lib.nerf_mlp_backward_packed_bytes(1, hip.PREC_BF16X2) == 0
     for fn in (lib.nerf_train_tape_bytes, lib.nerf_train_grad_tape_bytes):
         assert fn(100, 1, 7) == 0 and fn(-1, 1, f32) == 0
     assert lib.nerf_mlp_backward_packed_bytes(1, 7) == 0
