@@ -1,8 +1,9 @@
 """Camera-pose utilities on the host, either side of the render path: what turns an LLFF / Objectron
 ``poses_bounds.npy`` into the poses render() is called with and into the spiral or circle of poses render_path() is
 driven by (nerf-pytorch/load_llff.py:58-110, 126-316), the Blender-style pose on a sphere (load_blender.py:15-34),
-and a dependency-free PNG writer for render_path's frame dumps (run_nerf.py:170-175 uses imageio, which is optional
-here).  Pure numpy: this is host set-up work, done once per scene.
+and dependency-free writers for render_path's outputs: PNG frame dumps (run_nerf.py:170-175) and AVI videos
+(run_nerf.py:681, 819-820 write MP4); the reference uses imageio for both, which is optional here.  Pure numpy: this is
+host set-up work, done once per scene.
 """
 import struct
 import zlib
@@ -167,6 +168,101 @@ def pose_spherical(theta, phi, radius):
     import torch
     from .synth import pose_spherical as _ps
     return torch.from_numpy(_ps(theta, phi, radius))
+
+
+# ---------------------------------------------------------------------------- AVI (render_path's videos), no dependencies
+def write_avi(path, frames8, fps=30, jpeg_quality=None):
+    """frames8: uint8 [N,H,W,3] (or [N,H,W], written as grey RGB).  The reference writes its spiral / test-set videos
+    with imageio.mimwrite(..., fps=30, quality=8) as MP4 (run_nerf.py:681, 819-820), which needs imageio + ffmpeg; this
+    is the stand-in when they are absent: a RIFF/AVI file with one video stream, uncompressed 24-bit frames (any
+    player, lossless), or Motion-JPEG frames when `jpeg_quality` (1..100) is given and Pillow is importable."""
+    frames8 = np.ascontiguousarray(frames8)
+    if frames8.dtype != np.uint8 or frames8.ndim not in (3, 4) or (frames8.ndim == 4 and frames8.shape[3] != 3):
+        raise ValueError("write_avi expects uint8 [N,H,W,3] or [N,H,W], got %s %s" % (frames8.dtype, frames8.shape))
+    if frames8.ndim == 3:
+        frames8 = np.repeat(frames8[..., None], 3, axis=3)
+    n, h, w = frames8.shape[:3]
+    if n == 0:
+        raise ValueError("write_avi: no frames")
+    mjpg = False
+    if jpeg_quality is not None:
+        try:
+            from PIL import Image
+            import io
+            mjpg = True
+        except ImportError:
+            mjpg = False
+    chunks = []
+    for fr in frames8:
+        if mjpg:
+            buf = io.BytesIO()
+            Image.fromarray(fr).save(buf, format="JPEG", quality=int(jpeg_quality))
+            data = buf.getvalue()
+        else:      # bottom-up BGR rows, each padded to a multiple of 4 bytes
+            rows = fr[::-1, :, ::-1].reshape(h, w * 3)
+            pad = (-w * 3) % 4
+            data = (np.concatenate([rows, np.zeros((h, pad), np.uint8)], 1) if pad else rows).tobytes()
+        chunks.append(data)
+    tag = b"00dc" if mjpg else b"00db"
+    fourcc = b"MJPG" if mjpg else b"\0\0\0\0"
+    biggest = max(len(c) for c in chunks)
+
+    def riff_chunk(cid, body):
+        return cid + struct.pack("<I", len(body)) + body + (b"\0" if len(body) & 1 else b"")
+
+    def riff_list(kind, body):
+        return b"LIST" + struct.pack("<I", len(body) + 4) + kind + body
+
+    avih = struct.pack("<14I", int(round(1e6 / fps)), biggest * int(fps), 0, 0x10, n, 0, 1, biggest, w, h, 0, 0, 0, 0)
+    strh = b"vids" + (fourcc if mjpg else b"DIB ") + struct.pack("<IHHIIIIIIIIhhhh", 0, 0, 0, 0, 1, int(fps), 0, n, biggest,
+                                                                 0xffffffff, 0, 0, 0, w, h)
+    strf = struct.pack("<IiiHH", 40, w, h, 1, 24) + fourcc + struct.pack("<IiiII", biggest if mjpg else len(chunks[0]), 0, 0, 0, 0)
+    hdrl = riff_list(b"hdrl", riff_chunk(b"avih", avih) + riff_list(b"strl", riff_chunk(b"strh", strh) + riff_chunk(b"strf", strf)))
+    movi_body, index, off = b"", b"", 4
+    parts = []
+    for c in chunks:
+        parts.append(riff_chunk(tag, c))
+        index += tag + struct.pack("<III", 0x10, off, len(c))
+        off += len(parts[-1])
+    movi_body = b"".join(parts)
+    body = b"AVI " + hdrl + riff_list(b"movi", movi_body) + riff_chunk(b"idx1", index)
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def read_avi(path):
+    """Reads back what write_avi wrote: (frames uint8 [N,H,W,3], fps).  Motion-JPEG frames need Pillow."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"AVI ":
+        raise ValueError("%s is not an AVI file" % path)
+    w = h = fps = None
+    frames = []
+
+    def walk(lo, hi):
+        nonlocal w, h, fps
+        pos = lo
+        while pos + 8 <= hi:
+            cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+            body = pos + 8
+            if cid == b"LIST":
+                walk(body + 4, body + size)
+            elif cid == b"strh":
+                fps = struct.unpack("<I", data[body + 24:body + 28])[0] / struct.unpack("<I", data[body + 20:body + 24])[0]
+            elif cid == b"strf":
+                w, h = struct.unpack("<ii", data[body + 4:body + 12])
+            elif cid == b"00db":
+                stride = (w * 3 + 3) // 4 * 4
+                rows = np.frombuffer(data, np.uint8, stride * h, body).reshape(h, stride)[:, :w * 3]
+                frames.append(rows.reshape(h, w, 3)[::-1, :, ::-1].copy())
+            elif cid == b"00dc":
+                from PIL import Image
+                import io
+                frames.append(np.asarray(Image.open(io.BytesIO(data[body:body + size])).convert("RGB")))
+            pos = body + size + (size & 1)
+
+    walk(12, len(data))
+    return np.stack(frames, 0), fps
 
 
 # ---------------------------------------------------------------------------- PNG (8-bit RGB / grey), no dependencies

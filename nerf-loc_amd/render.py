@@ -374,6 +374,23 @@ def _save_frame(savedir, i, rgb, raw):
         np.save(os.path.join(savedir, '{:06d}.npy'.format(i)), raw.cpu().numpy())
 
 
+def write_video(path, frames, fps=30, quality=8):
+    """The video dumps of run_nerf.py:681, 819-820: imageio.mimwrite(path, to8b(frames), fps=30, quality=8).  frames:
+    float [N,H,W,3] in [0,1] (or uint8).  With imageio installed this is that call; without it an AVI file is written
+    next to the requested name (same stem, '.avi': uncompressed, or Motion-JPEG at quality 10 x `quality` when Pillow
+    is importable).  Returns the path written."""
+    frames8 = frames if getattr(frames, "dtype", None) == np.uint8 else to8b(np.asarray(frames))
+    try:
+        import imageio
+        imageio.mimwrite(path, frames8, fps=fps, quality=quality)
+        return path
+    except ImportError:
+        from .poses import write_avi
+        out = os.path.splitext(path)[0] + ".avi"
+        write_avi(out, frames8, fps=fps, jpeg_quality=min(100, 10 * int(quality)) if quality else None)
+        return out
+
+
 # ---------------------------------------------------------------------------- run_nerf.py:184-265
 def create_nerf(args, device=None):
     """Instantiate NeRF's MLP model(s), the query function, the optimizer, and

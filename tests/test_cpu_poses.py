@@ -112,3 +112,38 @@ def test_objectbank_reader_orders_and_checks_tensors(tmp_path):
     torch.save({'global_step': 0, 'network_fn_state_dict': {k: torch.from_numpy(v) for k, v in sd2.items()}}, path)
     with pytest.raises(ValueError):
         read_flat(path, layout, total)
+
+
+def test_avi_writer_round_trips(tmp_path):
+    """render_path's videos without imageio (run_nerf.py:681, 819-820 write MP4 through imageio + ffmpeg): the AVI
+    stand-in, uncompressed (exact) and Motion-JPEG (close), and write_video's choice of file."""
+    rs = np.random.RandomState(0)
+    frames = rs.randint(0, 256, size=(5, 12, 17, 3)).astype(np.uint8)          # odd width: rows are padded to 4 bytes
+    path = str(tmp_path / "raw.avi")
+    P.write_avi(path, frames, fps=30)
+    got, fps = P.read_avi(path)
+    assert fps == 30 and np.array_equal(got, frames)
+    data = open(path, "rb").read()
+    assert data[:4] == b"RIFF" and int.from_bytes(data[4:8], "little") == len(data) - 8 and b"idx1" in data
+    smooth = (np.linspace(0, 255, 32 * 48).reshape(1, 32, 48, 1) * np.ones((4, 1, 1, 3))).astype(np.uint8)
+    try:
+        import PIL  # noqa: F401
+        P.write_avi(str(tmp_path / "mj.avi"), smooth, fps=24, jpeg_quality=90)
+        got, fps = P.read_avi(str(tmp_path / "mj.avi"))
+        assert fps == 24 and got.shape == smooth.shape and np.abs(got.astype(int) - smooth.astype(int)).max() <= 6
+    except ImportError:
+        pass
+    with pytest.raises(ValueError):
+        P.write_avi(path, frames.astype(np.float32))
+    with pytest.raises(ValueError):
+        P.write_avi(path, frames[:0])
+    from nerf_loc_amd import render
+    out = render.write_video(str(tmp_path / "spiral_rgb.mp4"), smooth.astype(np.float32) / 255.0, fps=30, quality=8)
+    assert os.path.exists(out) and os.path.getsize(out) > 0
+    try:
+        import imageio  # noqa: F401
+        assert out.endswith(".mp4")
+    except ImportError:
+        assert out.endswith(".avi")
+        got, fps = P.read_avi(out)
+        assert fps == 30 and got.shape == smooth.shape
