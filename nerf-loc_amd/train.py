@@ -122,10 +122,31 @@ class _NetworkFn(torch.autograd.Function):
         return (None,) * 8 + tuple(g for g in grads if g is not None)
 
 
+# Samples one network call may carry in bf16x3: its kernels address the tapes with 32-bit byte offsets (1 KiB rows).
+MAX_SAMPLES_BF16X3 = 1 << 22
+
+
 def _network(model, mode, in0, in1, R, S, ray_cols):
     params = _params(model)
     slots = tuple(p is not None for p in params)
-    return _NetworkFn.apply(model, slots, mode, in0, in1, R, S, ray_cols, *[p for p in params if p is not None])
+    live = [p for p in params if p is not None]
+    if train_precision_of(model) == "bf16x3" and R * S > MAX_SAMPLES_BF16X3:
+        # more than one call's worth (the reference's batches are 1024-4096 rays; this is a 20 000-ray batch): whole rays
+        # per piece, one autograd node each, their gradients accumulate like any other
+        step = max(1, MAX_SAMPLES_BF16X3 // S)
+        outs = []
+        for lo in range(0, R, step):
+            n = min(step, R - lo)
+            if mode == hip.IN_RAYS:
+                a, b = in0[lo:lo + n], in1[lo:lo + n]
+            elif mode == hip.IN_POINTS:
+                a, b = in0[lo * S:(lo + n) * S], (None if in1 is None else in1[lo:lo + n])
+            else:
+                a, b = in0[lo * S:(lo + n) * S], None
+            outs.append(_NetworkFn.apply(model, slots, mode, a.contiguous(), None if b is None else b.contiguous(), n, S,
+                                         ray_cols, *live))
+        return torch.cat(outs, 0)
+    return _NetworkFn.apply(model, slots, mode, in0, in1, R, S, ray_cols, *live)
 
 
 class _CompositeFn(torch.autograd.Function):

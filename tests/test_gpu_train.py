@@ -527,3 +527,23 @@ def test_train_step_in_three_terms_matches_reference_autograd(dev, golden):
     wf = _grads_close(g, "det", "f", nf, 5e-3)
     print("bf16x3 training step: loss %.8f (reference %.8f), worst gradient error coarse %.2e, fine %.2e"
           % (float(loss.detach()), float(g["det_loss"]), wc, wf))
+
+
+def test_three_term_network_calls_are_cut_at_the_kernels_limit(dev, monkeypatch):
+    """bf16x3 kernels take at most 2^22 samples per call; train._network cuts larger batches into whole-ray pieces.
+    With the limit lowered to 1000 samples a 37-ray batch goes through in three pieces: same outputs bit for bit, same
+    gradients up to the summation order."""
+    from nerf_loc_amd import render, helpers, train
+    rays = T(synth.random_rays(37, seed=3), dev)
+    target = torch.rand(37, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    got = {}
+    for limit in (1 << 22, 1000):
+        monkeypatch.setattr(train, "MAX_SAMPLES_BF16X3", limit)
+        net = load_net(synth.make_state_dict(80, "B"), dev)
+        net.train_precision = "bf16x3"
+        r = render.render_rays(rays, net, _query(dev), 64, white_bkgd=True, perturb=0.0, raw_noise_std=0.0)
+        helpers.img2mse(r["rgb_map"], target).backward()
+        got[limit] = (r["rgb_map"].detach().clone(), {k: N(p.grad) for k, p in net.named_parameters()})
+    assert torch.equal(got[1000][0], got[1 << 22][0])
+    for k, g in got[1000][1].items():
+        assert relerr(g, got[1 << 22][1][k]) < 1e-5, k
