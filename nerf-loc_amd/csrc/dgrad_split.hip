@@ -79,7 +79,9 @@ __device__ __forceinline__ void dconvert_slice(const f32x4v (*src)[NCT], const M
     for (int t = 0; t < T; ++t) dst.v[ct][t][d] = w[t];
     if (d & 1) {
         const unsigned off = (gd.ld == 256 ? rc.rowb[ct] : rc.rowb[ct] >> 1) + rc.g16;
-        *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(gd.base) + off + 64 * tile) = make_float4(v[0], v[1], v[2], v[3]);
+        f32x4v* dstp = reinterpret_cast<f32x4v*>(reinterpret_cast<unsigned char*>(gd.base) + off + 64 * tile);
+        const f32x4v val = {v[0], v[1], v[2], v[3]};
+        *dstp = val;      // plain: a non-temporal store is 4 % faster here and costs the weight-gradient kernels more
     }
 }
 
@@ -264,8 +266,8 @@ void mlp_split_dgrad_kernel(SplitDgradArgs a) {
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = keep_if(acc[r], mA.w[ct][t >> 2], 8 * (t & 3) + r);
-                *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(a.gt.dz[0]) + rc.rowb[ct] + rc.g16 + 64 * t) =
-                    make_float4(v[0], v[1], v[2], v[3]);
+                const f32x4v val = {v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4v*>(reinterpret_cast<unsigned char*>(a.gt.dz[0]) + rc.rowb[ct] + rc.g16 + 64 * t) = val;
             }
         __builtin_amdgcn_sched_barrier(0);
     }
