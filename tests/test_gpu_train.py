@@ -327,7 +327,8 @@ def test_network_without_view_directions_trains(dev, output_ch):
     assert all(g is not None and torch.isfinite(g).all() for g in gs) and float(gs[0].abs().max()) > 0
 
 
-def test_train_step_without_view_directions_matches_reference_autograd(dev, golden):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_train_step_without_view_directions_matches_reference_autograd(dev, golden, precision):
     """The architecture with output_linear (5 rows, what create_nerf builds for N_importance > 0 without view
     directions: run_nerf.py:193) on 8-column rays: loss and gradients of one step against the reference's autograd
     (g17, run in float32 and float64).  The gradients of this step are 1e-5-sized sums that cancel; the reference's
@@ -338,6 +339,7 @@ def test_train_step_without_view_directions_matches_reference_autograd(dev, gold
     arch = dict(use_viewdirs=False, output_ch=5, input_ch_views=0)
     nc = load_net(synth.make_state_dict(170, "B", **arch), dev, use_viewdirs=False, output_ch=5)
     nf = load_net(synth.make_state_dict(171, "B", **arch), dev, use_viewdirs=False, output_ch=5)
+    nc.train_precision = nf.train_precision = precision
     q = render.NetworkQuery(helpers.get_embedder(10, 0)[0], None, 1024 * 64)
     rays, target = T(g["rays"], dev), T(g["target"], dev)
     r = render.render_rays(rays, nc, q, 64, N_importance=128, network_fine=nf, white_bkgd=True, retraw=True,
@@ -360,7 +362,7 @@ def test_train_step_without_view_directions_matches_reference_autograd(dev, gold
         print("  %s network: worst gradient error relative to the tensor's largest entry %.2e" % (pre, worst))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_gradient_exchange_direct_write_equals_autograd_path(dev, precision):
     """With a dist.GradientExchange the backward kernels write into views of one flat buffer and autograd sees no
     parameter gradients at all: same bits as the ordinary path (fresh tensors handed to autograd), .grad of every
