@@ -11,6 +11,7 @@ size_t split_packed_bytes(int terms, bool use_viewdirs);          // stream + bi
 int split_samples_per_tile();                                     // samples a workgroup takes per pass
 int launch_pack_split(const PackArgs& a, int terms, bool use_viewdirs, hipStream_t stream);
 int launch_mlp_split(const MlpArgs& a, int terms, bool use_viewdirs, int output_ch, unsigned grid, hipStream_t stream);
+int launch_mlp_split2(const MlpArgs& a, bool use_viewdirs, int output_ch, unsigned grid, hipStream_t stream);   // two terms
 // the training forward in three terms: as launch_mlp_split, and the float32 tape of tape.h is written (M <= 2^22 samples)
 int launch_mlp_split_train(const MlpArgs& a, const TapePtrs& tp, bool use_viewdirs, int output_ch, unsigned grid,
                            hipStream_t stream);
