@@ -456,6 +456,21 @@ def main(argv=None):
                                                     pmc_traffic(prec) if wl == "view" else None)}
             del x
             torch.cuda.empty_cache()
+        if world == 1:
+            # BASELINE configs[4] on this one GPU (the whole 4096-ray batch), in the reference's float32 and with forward
+            # and input gradients in three bf16 terms; `--workload train` is the data-parallel run
+            import copy
+            for tp in ("fp32", "bf16x3"):
+                a2 = copy.copy(args)
+                a2.train_precision = tp
+                x = make_workload("train", "fp32", a2, rank, world, device)
+                dtx, _, _ = timed(x["step"], 5, 2, world, device)
+                extras["train_4096_" + tp] = {"value": x["total_rays"] * 5 / dtx, "unit": "rays/s", "ms_per_step": dtx / 5 * 1e3,
+                                              "steps": 5, "warmup": 2, "dtype": DTYPE[tp], "workload": x["desc"]}
+                del x
+                torch.cuda.empty_cache()
+            from nerf_loc_amd import train as _train
+            _train.set_train_precision("fp32")
 
     if rank == 0:
         peak = PEAK_TFLOPS[precision]
